@@ -1,0 +1,172 @@
+/*
+ * y3.h -- C ABI of the MI355X-native YOLOv3 inference path (liby3hip.so).
+ *
+ * The reference (ronen-halevy/yolo-v3-tf2) has no FFI of its own: its operator surface is
+ * three Python callables and one Keras Layer that hand tensors to the TensorFlow runtime.
+ * This header declares the entry points a binding for that surface calls instead; each one
+ * cites the reference interface it replaces.  The ctypes binding the package itself uses is
+ * yolo-v3-tf2_amd/_lib.py; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns y3_status (0 = OK, <0 = error) and never
+ *     throws or aborts.  y3_last_error() returns a thread-local message for the last failure.
+ *   - "dev" pointers are device (HBM) addresses owned by the caller (e.g. torch `data_ptr()`);
+ *     "host" pointers are ordinary host memory, copied during the call.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises the device unless stated.  A y3_net is bound to the device that was current
+ *     at creation and is not thread-safe.
+ *   - tensors are NHWC fp32 unless stated; boxes are normalised (xmin,ymin,xmax,ymax).
+ */
+#ifndef Y3_H
+#define Y3_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int y3_status;
+enum {
+    Y3_OK = 0,
+    Y3_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    Y3_ERR_HIP = -2,       /* HIP runtime error */
+    Y3_ERR_OOM = -3,       /* device allocation failed */
+    Y3_ERR_STATE = -4,     /* call order (weights missing, plan missing, ...) */
+    Y3_ERR_NODEVICE = -5   /* no usable GPU */
+};
+
+/* activation storage / MFMA input type of the conv stack */
+enum { Y3_DTYPE_F32 = 0, Y3_DTYPE_BF16 = 1 };
+
+int y3_version(void);
+const char *y3_last_error(void);
+/* number of visible HIP devices (0 when none); never fails */
+int y3_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Network = the fused conv program.
+ * Replaces: the Keras Model built by ParseModel.build_model (reference: core/parse_model.py:279-314)
+ * and executed by model(inputs) / model.predict (reference: inference.py:109,125,161).
+ * One y3_conv_desc is one launch: Conv2D [+BatchNormalization] [+LeakyReLU(0.1)] [+Add] with the
+ * optional UpSampling2D(2)+Concatenate feeding a 1x1 conv read in place
+ * (reference: core/parse_model.py:13-56,59-75,102-160).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct y3_net y3_net;
+
+typedef struct {
+    int32_t size;          /* kernel size: 1 or 3 */
+    int32_t stride;        /* 1, or 2 (3x3 only: top/left zero pad then 'valid') */
+    int32_t cin;           /* total input channels */
+    int32_t cout;
+    int32_t bn;            /* 1: BatchNormalization(eps) after the conv, no bias; 0: bias */
+    int32_t leaky;         /* 1: LeakyReLU(alpha=0.1) */
+    int32_t src0;          /* tensor id of input channels [0, c0) */
+    int32_t src0_upsample; /* 1: src0 is half resolution and read through nearest x2 up-sampling */
+    int32_t c0;            /* channels taken from src0 (== cin when src1 < 0) */
+    int32_t src1;          /* -1, or tensor id of input channels [c0, cin) */
+    int32_t residual;      /* -1, or tensor id added after the activation (shortcut) */
+    int32_t dst;           /* tensor id written */
+    int32_t in_div;        /* input spatial size  = image_size / in_div  (after up-sampling) */
+    int32_t out_div;       /* output spatial size = image_size / out_div */
+} y3_conv_desc;
+
+/* auxiliary ops that the lowering could not fold into a conv (not used by YOLOv3 itself) */
+enum { Y3_AUX_ADD = 0, Y3_AUX_UPSAMPLE2X = 1, Y3_AUX_CONCAT = 2 };
+typedef struct {
+    int32_t kind;
+    int32_t src0;
+    int32_t src1; /* -1 for upsample */
+    int32_t dst;
+} y3_aux_desc;
+
+typedef struct {
+    int32_t channels;
+    int32_t div; /* spatial size = image_size / div */
+} y3_tensor_desc;
+
+/* op_kinds[i] == 0: take the next y3_conv_desc; == 1: take the next y3_aux_desc (execution order).
+ * tensors[0..n_tensors) describes every tensor id; `input_tensor` is the image, `outputs[3]` the head
+ * outputs in model order (coarsest grid first), each with 3*(5+nclasses) channels. */
+y3_status y3_net_create(const y3_tensor_desc *tensors, int n_tensors, const int32_t *op_kinds, int n_ops,
+                        const y3_conv_desc *convs, int n_convs, const y3_aux_desc *aux, int n_aux,
+                        int input_tensor, const int32_t outputs[3], int nclasses, y3_net **out);
+void y3_net_destroy(y3_net *net);
+
+/* Weights of conv `conv_slot` (index into the `convs` array given at creation), host pointers.
+ * w is HWIO [size,size,cin,cout] (the Keras Conv2D kernel layout, reference: convert.py:61-68).
+ * bn convs: gamma/beta/mean/var [cout], eps (Keras default 1e-3); bias convs: bias [cout], others NULL.
+ * Replaces model.load_weights(...) (reference: inference.py:102). */
+y3_status y3_net_set_conv_weights(y3_net *net, int conv_slot, const float *w, const float *gamma,
+                                  const float *beta, const float *mean, const float *var, const float *bias,
+                                  float eps);
+
+/* Tuning/testing knobs (no reference counterpart).
+ * y3_net_set_tile: force the block tile of one conv (index into the kernel's tile table; -1 = heuristic).
+ * y3_net_keep_activations(1) before y3_net_plan: no buffer reuse, so y3_net_read_tensor can read any
+ * intermediate after a forward. */
+y3_status y3_net_set_tile(y3_net *net, int conv_slot, int tile);
+y3_status y3_net_keep_activations(y3_net *net, int keep);
+
+/* Allocate the activation arena for batches up to `max_batch` of image_size x image_size inputs
+ * and select the conv arithmetic type (Y3_DTYPE_*).  May be called again to re-plan. */
+y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype);
+
+/* images_dev [B,S,S,3] fp32 -> grids_dev[3], each [B,g,g,3*(5+nc)] fp32 (== [B,g,g,3,5+nc]).
+ * Replaces model(inputs) (reference: inference.py:109). */
+y3_status y3_net_forward(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], void *stream);
+
+/* debugging / tests: copy tensor `tensor_id` of the last forward to dst_dev as fp32 (element count returned
+ * through *n_elems; dst_dev may be NULL to query the size) */
+y3_status y3_net_read_tensor(y3_net *net, int tensor_id, int batch, float *dst_dev, size_t *n_elems, void *stream);
+
+/* conv FLOPs (2*MAC) of one image at the planned size */
+double y3_net_flops_per_image(const y3_net *net);
+
+/* Time every conv launch of one forward (hipEvents on `stream`); ms_out[n_convs]. Synchronises. */
+y3_status y3_net_profile_convs(y3_net *net, const float *images_dev, int batch, float *ms_out, int n, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * yolo_decode   (reference: core/yolo_decode_layer.py:15-36)
+ * grids_dev[s]: [B,g_s,g_s,3,5+nc]; anchors_host: [3][3][2] normalised (w,h), scale s uses anchors[s].
+ * Outputs [B,N,4], [B,N,1], [B,N,nc] with N = 3*sum g_s^2, scales concatenated in input order.
+ * ---------------------------------------------------------------------------------------- */
+y3_status y3_yolo_decode(const float *const grids_dev[3], const int32_t grid_sizes[3], int batch, int nclasses,
+                         const float *anchors_host, float *bboxes_dev, float *conf_dev, float *probs_dev,
+                         void *stream);
+
+/* decode fused with the class arg-max / score of yolo_nms (reference: core/yolo_nms.py:18-24):
+ * writes bboxes [B,N,4], class_indices [B,N] int64, scores [B,N]; class probabilities are not stored. */
+y3_status y3_yolo_decode_scores(const float *const grids_dev[3], const int32_t grid_sizes[3], int batch,
+                                int nclasses, const float *anchors_host, float *bboxes_dev,
+                                int64_t *class_idx_dev, float *scores_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * yolo_nms / YoloNmsLayer.call   (reference: core/yolo_nms.py:16-34, core/yolo_nms_layer.py:26-29)
+ * ---------------------------------------------------------------------------------------- */
+/* class_indices = argmax(probs), scores = conf * max(probs)   (core/yolo_nms.py:18-24) */
+y3_status y3_class_scores(const float *conf_dev, const float *probs_dev, int batch, int n, int nclasses,
+                          int64_t *class_idx_dev, float *scores_dev, void *stream);
+
+/* bytes of scratch y3_nms_padded needs for (batch, n) */
+size_t y3_nms_workspace_bytes(int batch, int n);
+
+/* tf.image.non_max_suppression_padded(boxes[B,N,4], scores[B,N], max_output_size, iou_threshold,
+ * score_threshold, pad_to_max_output_size=True)   (core/yolo_nms.py:26-33)
+ * -> selected_idx [B,max_output_size] int32 (zero padded), num_valid [B] int32. */
+y3_status y3_nms_padded(const float *bboxes_dev, const float *scores_dev, int batch, int n, int max_output_size,
+                        float iou_threshold, float score_threshold, int32_t *selected_idx_dev,
+                        int32_t *num_valid_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* Inference.gather_valid_detections_results for a whole batch (reference: inference.py:21-28), packed for the
+ * multi-GPU exchange: per image max_out rows of {box[4], score, class (int32), index (int32)} = 7 x 4 bytes
+ * (rows >= num_valid zeroed), i.e. packed_dev is [B,max_out,7] of 32-bit words. */
+y3_status y3_pack_detections(const float *bboxes_dev, const int64_t *class_idx_dev, const float *scores_dev,
+                             const int32_t *selected_idx_dev, const int32_t *num_valid_dev, int batch, int n,
+                             int max_out, void *packed_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Y3_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of liby3hip.so (C ABI declared in include/y3.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails,
+`Y3Error` is raised.  Loading the library and resolving its symbols works without a GPU
+(used by the CPU test tier); any compute call needs one.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import PACKAGE_DIR
+
+LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "liby3hip.so")
+
+Y3_OK = 0
+Y3_DTYPE_F32, Y3_DTYPE_BF16 = 0, 1
+Y3_AUX_ADD, Y3_AUX_UPSAMPLE2X, Y3_AUX_CONCAT = 0, 1, 2
+TILE_NAMES = ["128x128", "256x64", "256x32", "128x64", "64x128", "64x64"]
+
+
+class Y3Error(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "size", "stride", "cin", "cout", "bn", "leaky", "src0", "src0_upsample", "c0", "src1", "residual", "dst",
+        "in_div", "out_div")]
+
+
+class AuxDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "src0", "src1", "dst")]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("div", C.c_int32)]
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_fp = C.POINTER(C.c_float)
+
+# every symbol include/y3.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "y3_version": (_i, []),
+    "y3_last_error": (C.c_char_p, []),
+    "y3_device_count": (_i, []),
+    "y3_net_create": (_i, [C.POINTER(TensorDesc), _i, C.POINTER(C.c_int32), _i, C.POINTER(ConvDesc), _i,
+                           C.POINTER(AuxDesc), _i, _i, C.POINTER(C.c_int32), _i, C.POINTER(_vp)]),
+    "y3_net_destroy": (None, [_vp]),
+    "y3_net_set_conv_weights": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f]),
+    "y3_net_set_tile": (_i, [_vp, _i, _i]),
+    "y3_net_keep_activations": (_i, [_vp, _i]),
+    "y3_net_plan": (_i, [_vp, _i, _i, _i]),
+    "y3_net_forward": (_i, [_vp, _vp, _i, C.POINTER(_vp), _vp]),
+    "y3_net_read_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_sz), _vp]),
+    "y3_net_flops_per_image": (C.c_double, [_vp]),
+    "y3_net_profile_convs": (_i, [_vp, _vp, _i, _fp, _i, _vp]),
+    "y3_yolo_decode": (_i, [C.POINTER(_vp), C.POINTER(C.c_int32), _i, _i, _fp, _vp, _vp, _vp, _vp]),
+    "y3_yolo_decode_scores": (_i, [C.POINTER(_vp), C.POINTER(C.c_int32), _i, _i, _fp, _vp, _vp, _vp, _vp]),
+    "y3_class_scores": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "y3_nms_workspace_bytes": (_sz, [_i, _i]),
+    "y3_nms_padded": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "y3_pack_detections": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liby3hip.so and bind every symbol; raises Y3Error when the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Y3Error(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                          f"(or yolo-v3-tf2_amd/csrc/build.py); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str = ""):
+    if status != Y3_OK:
+        msg = load().y3_last_error()
+        raise Y3Error(f"{what or 'y3 call'} failed ({status}): {msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available() or load().y3_device_count() < 1:
+        raise Y3Error("no MI355X/HIP device visible: the y3 kernels have no CPU fallback")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

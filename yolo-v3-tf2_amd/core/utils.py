@@ -1,0 +1,54 @@
+"""Host mirror of the helpers of reference core/utils.py that sit on the inference path."""
+import os
+
+import numpy as np
+
+
+def get_anchors(anchors_file):
+    """reference: core/utils.py:31-37 -- `loadtxt(delimiter=',')` then reshape(-1, 3, 2): row-major, so table[0] holds
+    the first three lines of the file (the largest anchors in the COCO file, used by the coarsest grid)."""
+    nanchors_per_scale = 3
+    anchor_entry_size = 2
+    anchors_table = np.loadtxt(anchors_file, dtype=float, delimiter=",")
+    return anchors_table.reshape(-1, nanchors_per_scale, anchor_entry_size)
+
+
+def dir_filelist(images_dir, ext_list=".*"):
+    """reference: core/utils.py:46-53"""
+    filenames = []
+    for f in os.listdir(images_dir):
+        ext = os.path.splitext(f)[1]
+        if ext.lower() not in ext_list:
+            continue
+        filenames.append(f"{images_dir}/{f}")
+    return filenames
+
+
+def resize_bilinear(img, out_h, out_w):
+    """tf.image.resize(img, (out_h, out_w)) default method (bilinear, antialias=False, half-pixel centres) for one
+    HWC float32 image -- reference call site: inference.py:158.  Rows then columns, fp32."""
+    img = np.asarray(img, np.float32)
+    in_h, in_w = img.shape[0], img.shape[1]
+
+    def taps(n_in, n_out):
+        scale = np.float32(n_in) / np.float32(n_out)
+        src = (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) * scale - np.float32(0.5)
+        fl = np.floor(src)
+        lo = np.maximum(fl, 0).astype(np.int64)
+        hi = np.minimum(np.ceil(src), n_in - 1).astype(np.int64)
+        return lo, hi, (src - fl).astype(np.float32)
+
+    lo, hi, fr = taps(in_h, out_h)
+    rows = img[lo] + (img[hi] - img[lo]) * fr[:, None, None]
+    lo, hi, fr = taps(in_w, out_w)
+    return (rows[:, lo] + (rows[:, hi] - rows[:, lo]) * fr[None, :, None]).astype(np.float32)
+
+
+def load_image_rgb01(path):
+    """tf.image.decode_image(bytes, channels=3, dtype=float32): RGB, alpha dropped, uint8/255 -> [0,1]
+    (reference: inference.py:157)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        im = im.convert("RGBA") if im.mode in ("RGBA", "LA", "P") else im.convert("RGB")
+        a = np.asarray(im, np.uint8)[..., :3]
+    return a.astype(np.float32) / np.float32(255.0)

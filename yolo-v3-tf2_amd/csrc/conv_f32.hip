@@ -1,0 +1,342 @@
+// fp32 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces Conv2D -> BatchNormalization -> LeakyReLU(0.1) [-> Add] of the reference graph
+// (reference: core/parse_model.py:27-52,155-156) and the UpSampling2D + Concatenate feeding the
+// lateral 1x1 convs (reference: core/parse_model.py:72,134) with ONE launch per conv.
+//
+// GEMM view: M = B*Ho*Wo output pixels (NHWC order), N = Cout, K = taps*Cin with k = tap*Cin + c.
+//   A[m][k]  = input pixel (ho*s-pad+u, wo*s-pad+v) channel c, gathered on the fly (zero outside)
+//   B[n][k]  = packed weights [CoutPad][K]
+// Block tile BM x BN x 32, 256 threads = 4 waves (one per SIMD), wave tile (32*TM) x (32*TN).
+// Both operand tiles live in LDS as [rows][32+4] floats (K contiguous, one 16-B pad per row:
+// row stride 9 x 16 B makes every ds_read_b128 of 16 different rows conflict-free), filled with
+// 16-B buffer loads -> ds_write_b128 and double buffered (one barrier per K tile).
+// A lane reads 4 consecutive k of its row as one ds_read_b128 and feeds them to 4 MFMAs; lanes
+// 0-31 / 32-63 take k = 8q+t / 8q+4+t in MFMA (q,t), identically for A and B, so every k is
+// contracted exactly once (the order of k inside a tile is irrelevant to the sum's value up to
+// fp32 rounding).
+// Epilogue from the accumulators: y = acc*scale[n] + shift[n]; leaky; + residual; store.
+#include "y3_kernels.h"
+
+namespace y3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BK = 32;
+static constexpr int LDS_ROW = BK + 4;  // floats
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff)
+{
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+template <int TM, int TN, int WR, int WC, bool CONCAT>
+__global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
+{
+    constexpr int BM = 32 * TM * WR;
+    constexpr int BN = 32 * TN * WC;
+    constexpr int AP = BM / 32;  // A load passes (32 rows x 8 lanes of 16 B per pass)
+    constexpr int BP = BN / 32;
+    constexpr int STAGE = (BM + BN) * LDS_ROW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+    // run of logical tiles so that the N-tiles of one pixel tile and neighbouring pixel tiles meet
+    // in one L2.  Bijective for any grid size.
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tilesN = p.CoutPad / BN;
+    const int mt = logical / tilesN, nt = logical - mt * tilesN;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.src0), 0, p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(CONCAT ? p.src1 : p.src0), 0, CONCAT ? p.src1_bytes : p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wpk), 0, p.w_bytes, 0x00020000);
+    // a voffset equal to num_records is out of range for the buffer's bounds check -> the load returns 0
+    const unsigned OOB0 = p.src0_bytes, OOB1 = CONCAT ? p.src1_bytes : p.src0_bytes;
+
+    // ---- per-thread gather state -------------------------------------------------------------
+    const int lrow = tid >> 3;         // row inside a pass
+    const int lchunk = (tid & 7) * 4;  // first float of this lane's 16-B piece inside the 32-float K tile
+    int aoff[AP];                      // element offset of (b, hi0, wi0, 0) in src0 (may be negative)
+    int aoff1[CONCAT ? AP : 1];        // CONCAT: element offset of (b, ho, wo, 0) in src1
+    int ahw[AP];                       // hi0 << 16 | (wi0 & 0xffff); row >= M marked by hi0 = -32768
+    const int HoWo = p.Ho * p.Wo;
+    const int C1 = p.Cin - p.C0;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + i * 32 + lrow;
+        int b = m / HoWo;
+        int r = m - b * HoWo;
+        int ho = r / p.Wo;
+        int wo = r - ho * p.Wo;
+        if (CONCAT) {
+            // 1x1 conv: src0 optionally read through nearest x2 up-sampling
+            const int H0 = p.up0 ? (p.H >> 1) : p.H, W0 = p.up0 ? (p.W >> 1) : p.W;
+            const int h0 = p.up0 ? (ho >> 1) : ho, w0 = p.up0 ? (wo >> 1) : wo;
+            aoff[i] = ((b * H0 + h0) * W0 + w0) * p.C0;
+            aoff1[i] = ((b * p.H + ho) * p.W + wo) * C1;
+            ahw[i] = (m < p.M) ? 0 : (int)0x80000000;
+        } else {
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            aoff[i] = ((b * p.H + hi0) * p.W + wi0) * p.Cin;
+            ahw[i] = (m < p.M) ? ((hi0 << 16) | (wi0 & 0xffff)) : (int)0x80000000;
+        }
+    }
+    unsigned boff[BP];  // byte offset of this lane's piece of weight row n, k = 0
+#pragma unroll
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * 32 + lrow) * p.K + lchunk) * 4);
+
+    // walking state of the *next* K tile to fetch
+    int tap = 0, c0 = 0;
+    unsigned avoff[AP];  // byte offset for the current tap
+    unsigned amask = 0;  // bit i: row i of this tap lies inside the image (and m < M)
+    auto set_tap = [&]() {
+        amask = 0;
+        if (CONCAT) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                avoff[i] = (unsigned)((aoff[i] + lchunk) * 4);
+                amask |= (ahw[i] < 0 ? 0u : 1u) << i;
+            }
+        } else {
+            const int u = tap / p.ksize, v = tap - u * p.ksize;
+            const int toff = (u * p.W + v) * p.Cin + lchunk;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                avoff[i] = (unsigned)((aoff[i] + toff) * 4);
+                amask |= (ok ? 1u : 0u) << i;
+            }
+        }
+    };
+    set_tap();
+
+    f32x4 ra[AP], rb[BP];
+    int kglob = 0;  // k index of the next tile to fetch
+    auto fetch = [&]() {
+        if (CONCAT) {
+            // channels [0,C0) come from src0, [C0,Cin) from src1; a 32-wide K tile never straddles (C0 % 32 == 0)
+            if (c0 < p.C0) {
+#pragma unroll
+                for (int i = 0; i < AP; ++i) ra[i] = buf_load16(rs0, (amask >> i) & 1 ? avoff[i] + c0 * 4 : OOB0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < AP; ++i)
+                    ra[i] = buf_load16(rs1, (amask >> i) & 1 ? (unsigned)((aoff1[i] + lchunk + (c0 - p.C0)) * 4) : OOB1);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) ra[i] = buf_load16(rs0, (amask >> i) & 1 ? avoff[i] + c0 * 4 : OOB0);
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) rb[j] = buf_load16(rsw, boff[j] + kglob * 4);
+        kglob += BK;
+        c0 += BK;
+        if (c0 == p.Cin) {
+            c0 = 0;
+            ++tap;
+            if (!CONCAT) set_tap();
+        }
+    };
+    auto stage = [&](int buf) {
+        float *sa = smem + buf * STAGE;
+        float *sb = sa + BM * LDS_ROW;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4 *>(sa + (i * 32 + lrow) * LDS_ROW + lchunk) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BP; ++j) *reinterpret_cast<f32x4 *>(sb + (j * 32 + lrow) * LDS_ROW + lchunk) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int KT = p.K / BK;
+    fetch();
+    stage(0);
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int a_frag = (wr * 32 * TM + fr) * LDS_ROW + fh * 4;
+    const int b_frag = BM * LDS_ROW + (wc * 32 * TN + fr) * LDS_ROW + fh * 4;
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) fetch();
+        const float *sa = smem + cur * STAGE + a_frag;
+        const float *sb = smem + cur * STAGE + b_frag;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(sa + i * 32 * LDS_ROW + q * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(sb + j * 32 * LDS_ROW + q * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+    // accumulator element e of lane l: column (n) = l & 31, row (m) = (e & 3) + 8*(e >> 2) + 4*(l >> 5)
+    float *dst = static_cast<float *>(p.dst);
+    const float *res = static_cast<const float *>(p.residual);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wc * TN + j) * 32 + fr;
+        const float sc = p.scale[n], sh = p.shift[n];
+        const bool n_ok = n < p.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mbase = m0 + (wr * TM + i) * 32 + 4 * fh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mbase + (e & 3) + 8 * (e >> 2);
+                if (n_ok && m < p.M) {
+                    float v = acc[i][j][e] * sc + sh;
+                    if (p.leaky) v = (v >= 0.0f) ? v : 0.1f * v;
+                    const size_t o = (size_t)m * p.Cout + n;
+                    if (res) v = res[o] + v;
+                    dst[o] = v;
+                }
+            }
+        }
+    }
+}
+
+TileShape conv_tile_shape(int tile)
+{
+    switch (tile) {
+        case TILE_128x128: return {128, 128};
+        case TILE_256x64: return {256, 64};
+        case TILE_256x32: return {256, 32};
+        case TILE_128x64: return {128, 64};
+        case TILE_64x128: return {64, 128};
+        default: return {64, 64};
+    }
+}
+
+template <int TM, int TN, int WR, int WC>
+static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
+{
+    constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
+    const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
+    dim3 grid(tilesM * tilesN), block(256);
+    if (a.src1) {
+        auto k = conv_f32_mfma<TM, TN, WR, WC, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, s, a);
+    } else {
+        auto k = conv_f32_mfma<TM, TN, WR, WC, false>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
+{
+    switch (tile) {
+        case TILE_128x128: return launch_t<2, 2, 2, 2>(a, s);
+        case TILE_256x64: return launch_t<2, 2, 4, 1>(a, s);
+        case TILE_256x32: return launch_t<2, 1, 4, 1>(a, s);
+        case TILE_128x64: return launch_t<1, 2, 4, 1>(a, s);
+        case TILE_64x128: return launch_t<1, 2, 2, 2>(a, s);
+        case TILE_64x64: return launch_t<1, 1, 2, 2>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// First layer: 3x3 / stride 1 / Cin = 3 / Cout = 32 (K = 27 is too thin for the MFMA tile and the
+// layer is bound by its 4*Cout bytes of output per pixel).  One thread = one output pixel x all
+// output channels; weights are wave-uniform (scalar loads), accumulation order (u,v,c) like the
+// GEMM kernel's k order.
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_first_f32(const ConvArgs p, const float *__restrict__ w)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= p.M) return;
+    const int HW = p.H * p.W;
+    const int b = m / HW;
+    const int r = m - b * HW;
+    const int ho = r / p.W, wo = r - ho * p.W;
+    const float *x = static_cast<const float *>(p.src0);
+    float acc[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
+#pragma unroll 1
+    for (int u = 0; u < 3; ++u) {
+        const int hi = ho - 1 + u;
+#pragma unroll 1
+        for (int v = 0; v < 3; ++v) {
+            const int wi = wo - 1 + v;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float *xp = x + ((size_t)(b * p.H + (ok ? hi : 0)) * p.W + (ok ? wi : 0)) * 3;
+            float xv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xv[c] = ok ? xp[c] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *wr = w + ((u * 3 + v) * 3 + c) * COUT;  // HWIO, wave-uniform address
+#pragma unroll
+                for (int n = 0; n < COUT; ++n) acc[n] += xv[c] * wr[n];
+            }
+        }
+    }
+    float *dst = static_cast<float *>(p.dst) + (size_t)m * COUT;
+#pragma unroll
+    for (int n = 0; n < COUT; n += 4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[n + e] * p.scale[n + e] + p.shift[n + e];
+            if (p.leaky) v = (v >= 0.0f) ? v : 0.1f * v;
+            o[e] = v;
+        }
+        *reinterpret_cast<f32x4 *>(dst + n) = o;
+    }
+}
+
+hipError_t launch_conv_first_f32(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s)
+{
+    if (a.Cin != 3 || a.ksize != 3 || a.stride != 1 || a.Cout != 32 || a.residual || a.src1)
+        return hipErrorInvalidValue;
+    dim3 grid((a.M + 255) / 256), block(256);
+    hipLaunchKernelGGL(conv_first_f32<32>, grid, block, 0, s, a, w_hwio_dev);
+    return hipGetLastError();
+}
+
+}  // namespace y3

@@ -1,0 +1,311 @@
+// tf.image.non_max_suppression_padded (tiled "v2" semantics) + detection packing on gfx950.
+//
+// Replaces the call in reference core/yolo_nms.py:26-33 and the per-image gathers of
+// reference inference.py:21-28.  Semantics restated in SURVEY.md Appendix B.4 and oracle/y3_oracle.c:
+//   1. boxes/scores with score <= S are zeroed (multiplication by the mask);
+//   2. coordinate canonicalisation decided by box [0,0] of the batch only;
+//   3. descending sort by score, ties by lower original index;
+//   4. greedy suppression in sorted order, suppress when IoU >= T (fp32, TF's association order,
+//      union + 1e-8); zeroed boxes have IoU 0 with everything;
+//   5. a survivor is *selected* iff any of its coordinates is > 0; the first M selected positions
+//      are returned as original indices (int32), the rest of the row is 0; num_valid = min(count, M).
+// One workgroup (256 threads) per image: threshold+compact -> bitonic sort of 64-bit
+// (score desc, index asc) keys in LDS (global scratch beyond 4096 candidates) -> chunks of 256
+// candidates: every lane tests its candidate against the kept list (LDS), builds its 256-bit
+// intra-chunk suppression row, and wave 0 resolves the chunk serially with scalar bit-ops.
+// Integer/index work is exact; IoU arithmetic is fp32 without contraction.
+#include "y3_kernels.h"
+
+namespace y3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+static constexpr int NMS_THREADS = 256;
+static constexpr int SORT_CAP = 4096;   // keys sorted in LDS
+static constexpr int KEPT_CAP = 2048;   // surviving suppressor boxes held in LDS
+
+__device__ __forceinline__ unsigned score_key(float s)
+{
+    s = s + 0.0f;  // -0 -> +0 so that equal floats give equal keys
+    unsigned u = __float_as_uint(s);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // ascending float order
+    return ~u;                                   // descending
+}
+
+__device__ __forceinline__ float iou_tf(const f32x4 a, const f32x4 b)
+{
+    const float i_xmin = fmaxf(a[1], b[1]), i_xmax = fminf(a[3], b[3]);
+    const float i_ymin = fmaxf(a[0], b[0]), i_ymax = fminf(a[2], b[2]);
+    const float i_area = fmaxf(i_xmax - i_xmin, 0.0f) * fmaxf(i_ymax - i_ymin, 0.0f);
+    const float a_area = (a[2] - a[0]) * (a[3] - a[1]);
+    const float b_area = (b[2] - b[0]) * (b[3] - b[1]);
+    const float u_area = a_area + b_area - i_area + 1e-8f;
+    return i_area / u_area;
+}
+
+__device__ void bitonic_sort(u64 *keys, int P, int tid)
+{
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += NMS_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // element with bit j clear
+                const int l = i | j;
+                const bool up = (i & k) == 0;
+                const u64 a = keys[i], b = keys[l];
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct NmsArgs {
+    const float *boxes;   // [B,N,4]
+    const float *scores;  // [B,N]
+    int N, M;
+    float T, S;
+    int32_t *sel;         // [B,M]
+    int32_t *num_valid;   // [B]
+    u64 *ws;              // [B][P2] scratch keys, P2 = next pow2 >= N
+    int P2;
+};
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
+{
+    __shared__ __attribute__((aligned(16))) u64 s_keys[SORT_CAP];
+    __shared__ __attribute__((aligned(16))) float s_kbox[KEPT_CAP * 4];
+    __shared__ __attribute__((aligned(16))) float s_cbox[NMS_THREADS * 4];
+    __shared__ u64 s_mask[NMS_THREADS * 4];
+    __shared__ u64 s_alive[4];
+    __shared__ int s_keptpos[NMS_THREADS];
+    __shared__ int s_cnt, s_nkept_chunk, s_nsel, s_nalive, s_overflow;
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const float *boxes = p.boxes + (size_t)b * p.N * 4;
+    const float *scores = p.scores + (size_t)b * p.N;
+    int32_t *sel = p.sel + (size_t)b * p.M;
+    u64 *gkeys = p.ws + (size_t)b * p.P2;
+
+    // canonicalisation flags from box [0,0] of the batch after masking (TF looks at that box only)
+    const float m00 = (p.scores[0] > p.S) ? 1.0f : 0.0f;
+    const bool swap_y = !(p.boxes[0] * m00 <= p.boxes[2] * m00);
+    const bool swap_x = !(p.boxes[1] * m00 <= p.boxes[3] * m00);
+
+    if (tid == 0) {
+        s_cnt = 0;
+        s_nsel = 0;
+        s_nalive = 0;
+        s_overflow = 0;
+    }
+    for (int i = tid; i < p.M; i += NMS_THREADS) sel[i] = 0;
+    __syncthreads();
+
+    // ---- 1. threshold + compact (order irrelevant: the sort key carries the index) -----------------
+    for (int i = tid; i < p.N; i += NMS_THREADS) {
+        const float s = scores[i];
+        if (s > p.S) {
+            const int slot = atomicAdd(&s_cnt, 1);
+            gkeys[slot] = ((u64)score_key(s) << 32) | (unsigned)i;
+        }
+    }
+    __syncthreads();
+    const int nc = s_cnt;
+    // ---- 2. sort ------------------------------------------------------------------------------------
+    int P = 1;
+    while (P < nc) P <<= 1;
+    u64 *keys;
+    if (P <= SORT_CAP) {
+        for (int i = tid; i < P; i += NMS_THREADS) s_keys[i] = (i < nc) ? gkeys[i] : ~0ull;
+        keys = s_keys;
+    } else {
+        for (int i = nc + tid; i < P; i += NMS_THREADS) gkeys[i] = ~0ull;
+        keys = gkeys;
+    }
+    __syncthreads();
+    bitonic_sort(keys, P, tid);
+
+    // ---- 3. greedy suppression, 256 sorted candidates at a time ---------------------------------------
+    for (int pos = 0; pos < nc; pos += NMS_THREADS) {
+        const int cnt = min(NMS_THREADS, nc - pos);
+        const int nalive = s_nalive;
+        f32x4 mine = {0.f, 0.f, 0.f, 0.f};
+        int my_idx = 0;
+        bool ok = false;
+        if (tid < cnt) {
+            my_idx = (int)(unsigned)(keys[pos + tid] & 0xFFFFFFFFull);
+            mine = *reinterpret_cast<const f32x4 *>(boxes + (size_t)my_idx * 4);
+            if (swap_y) { const float t = mine[0]; mine[0] = mine[2]; mine[2] = t; }
+            if (swap_x) { const float t = mine[1]; mine[1] = mine[3]; mine[3] = t; }
+            ok = true;
+            for (int a = 0; a < nalive; ++a)
+                if (iou_tf(*reinterpret_cast<const f32x4 *>(s_kbox + a * 4), mine) >= p.T) ok = false;
+        }
+        *reinterpret_cast<f32x4 *>(s_cbox + tid * 4) = mine;
+        const u64 bal = __ballot(ok);
+        if ((tid & 63) == 0) s_alive[tid >> 6] = bal;
+        __syncthreads();
+        // suppression row of this candidate over the later candidates of the chunk
+        u64 row[4] = {0, 0, 0, 0};
+        if (ok) {
+            for (int j = tid + 1; j < cnt; ++j) {
+                if (iou_tf(mine, *reinterpret_cast<const f32x4 *>(s_cbox + j * 4)) >= p.T) row[j >> 6] |= 1ull << (j & 63);
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s_mask[tid * 4 + w] = row[w];
+        __syncthreads();
+        if (tid < 64) {
+            // wave 0, every lane redundantly (uniform control flow): walk the alive bits in order
+            u64 w0 = s_alive[0], w1 = s_alive[1], w2 = s_alive[2], w3 = s_alive[3];
+            int nsel = s_nsel, nk = 0, nal = nalive;
+            bool full = false;
+            for (int w = 0; w < 4 && !full; ++w) {
+                u64 rem = (w == 0) ? w0 : (w == 1) ? w1 : (w == 2) ? w2 : w3;
+                while (rem) {
+                    const int i = __builtin_ctzll(rem);
+                    const int t = w * 64 + i;
+                    if (nal >= KEPT_CAP) {
+                        if (tid == 0) s_overflow = 1;
+                        full = true;
+                        break;
+                    }
+                    if (tid == 0) s_keptpos[nk] = t;
+                    ++nk;
+                    ++nal;
+                    const f32x4 cb = *reinterpret_cast<const f32x4 *>(s_cbox + t * 4);
+                    if (cb[0] > 0.0f || cb[1] > 0.0f || cb[2] > 0.0f || cb[3] > 0.0f) {
+                        if (tid == 0) sel[nsel] = (int32_t)(unsigned)(keys[pos + t] & 0xFFFFFFFFull);
+                        ++nsel;
+                        if (nsel >= p.M) {
+                            full = true;
+                            break;
+                        }
+                    }
+                    w0 &= ~s_mask[t * 4 + 0];
+                    w1 &= ~s_mask[t * 4 + 1];
+                    w2 &= ~s_mask[t * 4 + 2];
+                    w3 &= ~s_mask[t * 4 + 3];
+                    const u64 cur = (w == 0) ? w0 : (w == 1) ? w1 : (w == 2) ? w2 : w3;
+                    rem = (i == 63) ? 0ull : (cur & ~((2ull << i) - 1ull));
+                }
+            }
+            if (tid == 0) {
+                s_nsel = nsel;
+                s_nkept_chunk = nk;
+            }
+        }
+        __syncthreads();
+        const int nk = s_nkept_chunk;
+        if (tid < nk) {
+            const int t = s_keptpos[tid];
+            *reinterpret_cast<f32x4 *>(s_kbox + (nalive + tid) * 4) = *reinterpret_cast<const f32x4 *>(s_cbox + t * 4);
+        }
+        if (tid == 0) s_nalive = nalive + nk;
+        __syncthreads();
+        if (s_nsel >= p.M || s_overflow) break;
+    }
+    if (tid == 0) p.num_valid[b] = s_overflow ? -1 : s_nsel;
+}
+
+// iou_threshold <= 0: the box at sorted position 0 suppresses every other box (IoU >= T always holds);
+// that box is selected iff it passed the score filter and has a positive coordinate.
+__global__ __launch_bounds__(NMS_THREADS) void nms_degenerate_kernel(const NmsArgs p)
+{
+    __shared__ u64 s_best[NMS_THREADS];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float *scores = p.scores + (size_t)b * p.N;
+    int32_t *sel = p.sel + (size_t)b * p.M;
+    u64 best = ~0ull;
+    for (int i = tid; i < p.N; i += NMS_THREADS) {
+        const float s = scores[i];
+        const float ms = (s > p.S) ? s : s * 0.0f;
+        const u64 k = ((u64)score_key(ms) << 32) | (unsigned)i;
+        best = k < best ? k : best;
+    }
+    s_best[tid] = best;
+    for (int i = tid; i < p.M; i += NMS_THREADS) sel[i] = 0;
+    __syncthreads();
+    for (int st = NMS_THREADS / 2; st > 0; st >>= 1) {
+        if (tid < st) s_best[tid] = s_best[tid + st] < s_best[tid] ? s_best[tid + st] : s_best[tid];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int nv = 0;
+        if (p.N > 0 && p.M > 0) {
+            const int i = (int)(unsigned)(s_best[0] & 0xFFFFFFFFull);
+            if (scores[i] > p.S) {
+                const float *bx = p.boxes + ((size_t)b * p.N + i) * 4;
+                if (bx[0] > 0.0f || bx[1] > 0.0f || bx[2] > 0.0f || bx[3] > 0.0f) {
+                    sel[0] = i;
+                    nv = 1;
+                }
+            }
+        }
+        p.num_valid[b] = nv;
+    }
+}
+
+static int next_pow2(int n)
+{
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+size_t nms_workspace_bytes(int B, int N) { return (size_t)B * next_pow2(N > 1 ? N : 1) * sizeof(u64); }
+
+hipError_t launch_nms(const float *boxes, const float *scores, int B, int N, int M, float T, float S, int32_t *sel,
+                      int32_t *num_valid, void *ws, hipStream_t s)
+{
+    NmsArgs a{boxes, scores, N, M, T, S, sel, num_valid, static_cast<u64 *>(ws), next_pow2(N > 1 ? N : 1)};
+    dim3 grid(B), block(NMS_THREADS);
+    if (T > 0.0f)
+        hipLaunchKernelGGL(nms_kernel, grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL(nms_degenerate_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+// Batched Inference.gather_valid_detections_results (reference: inference.py:21-28), packed rows
+// {xmin, ymin, xmax, ymax, score, class, index}; rows >= num_valid are zero.
+__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ boxes, const int64_t *__restrict__ cls,
+                                                   const float *__restrict__ scores, const int32_t *__restrict__ sel,
+                                                   const int32_t *__restrict__ nv, int B, int N, int M,
+                                                   unsigned *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * M) return;
+    const int b = i / M, r = i - b * M;
+    unsigned *o = out + (size_t)i * 7;
+    if (r < nv[b]) {
+        const int idx = sel[i];
+        const size_t g = (size_t)b * N + idx;
+        const float *bx = boxes + g * 4;
+        o[0] = __float_as_uint(bx[0]);
+        o[1] = __float_as_uint(bx[1]);
+        o[2] = __float_as_uint(bx[2]);
+        o[3] = __float_as_uint(bx[3]);
+        o[4] = __float_as_uint(scores[g]);
+        o[5] = (unsigned)(int)cls[g];
+        o[6] = (unsigned)idx;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = 0;
+    }
+}
+
+hipError_t launch_pack(const float *boxes, const int64_t *cls, const float *scores, const int32_t *sel,
+                       const int32_t *nv, int B, int N, int M, void *packed, hipStream_t s)
+{
+    dim3 grid((B * M + 255) / 256), block(256);
+    hipLaunchKernelGGL(pack_kernel, grid, block, 0, s, boxes, cls, scores, sel, nv, B, N, M,
+                       static_cast<unsigned *>(packed));
+    return hipGetLastError();
+}
+
+}  // namespace y3

@@ -1,0 +1,560 @@
+// C-ABI layer of liby3hip.so: network object (fused conv program), weight packing, activation arena,
+// and the decode / NMS entry points.  See include/y3.h for the contract each function implements and
+// the reference interface it replaces.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/y3.h"
+#include "y3_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? Y3_ERR_OOM : Y3_ERR_HIP, "%s: %s", #expr,     \
+                        hipGetErrorString(e_));                                                   \
+    } while (0)
+
+struct ConvSlot {
+    y3_conv_desc d{};
+    bool loaded = false;
+    bool first_layer = false;  // Cin == 3 direct kernel
+    int cout_pad = 0;
+    int K = 0;
+    int tile = -1;             // -1: choose by heuristic at plan time
+    float *w_dev = nullptr;    // packed [CoutPad][K] (or HWIO for the first layer)
+    float *scale_dev = nullptr;
+    float *shift_dev = nullptr;
+};
+
+struct Op {
+    int kind;  // 0 conv, 1 aux
+    int index;
+};
+
+}  // namespace
+
+struct y3_net {
+    int device = 0;
+    std::vector<y3_tensor_desc> tensors;
+    std::vector<Op> ops;
+    std::vector<ConvSlot> convs;
+    std::vector<y3_aux_desc> aux;
+    int input_tensor = 0;
+    int outputs[3] = {0, 0, 0};
+    int nclasses = 0;
+    // plan
+    int max_batch = 0, image_size = 0, dtype = Y3_DTYPE_F32;
+    int keep_all = 0;              // 1: no buffer reuse, every intermediate stays readable after a forward
+    std::vector<void *> tdev;      // arena pointer per tensor (nullptr: not materialised / external)
+    std::vector<size_t> tbytes;    // bytes at max_batch
+    std::vector<void *> blocks;    // distinct hipMalloc'ed blocks
+};
+
+namespace {
+
+int spatial(const y3_net *n, int t) { return n->image_size / n->tensors[t].div; }
+
+void free_plan(y3_net *n)
+{
+    for (void *p : n->blocks) (void)hipFree(p);
+    n->blocks.clear();
+    n->tdev.assign(n->tensors.size(), nullptr);
+}
+
+int choose_tile(const ConvSlot &c, long long M)
+{
+    using namespace y3;
+    std::vector<int> cand;
+    if (c.cout_pad % 128 == 0)
+        cand = {TILE_128x128, TILE_64x128, TILE_64x64};
+    else if (c.cout_pad % 64 == 0)
+        cand = {TILE_256x64, TILE_128x64, TILE_64x64};
+    else
+        cand = {TILE_256x32};
+    int best = cand.back();
+    for (int t : cand) {
+        TileShape s = conv_tile_shape(t);
+        long long blocks = ((M + s.bm - 1) / s.bm) * (c.cout_pad / s.bn);
+        if (blocks >= 512) {  // two workgroups per CU
+            best = t;
+            break;
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+int y3_version(void) { return 100; }
+
+const char *y3_last_error(void) { return g_err.c_str(); }
+
+int y3_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+y3_status y3_net_create(const y3_tensor_desc *tensors, int n_tensors, const int32_t *op_kinds, int n_ops,
+                        const y3_conv_desc *convs, int n_convs, const y3_aux_desc *aux, int n_aux, int input_tensor,
+                        const int32_t outputs[3], int nclasses, y3_net **out)
+{
+    if (!tensors || !op_kinds || !convs || !outputs || !out || n_tensors <= 0 || n_ops <= 0)
+        return fail(Y3_ERR_INVALID, "y3_net_create: null or empty argument");
+    auto net = new y3_net();
+    if (hipGetDevice(&net->device) != hipSuccess) {
+        delete net;
+        return fail(Y3_ERR_NODEVICE, "y3_net_create: no HIP device");
+    }
+    net->tensors.assign(tensors, tensors + n_tensors);
+    net->aux.assign(aux, aux + (aux ? n_aux : 0));
+    net->convs.resize(n_convs);
+    auto bad_t = [&](int t) { return t < 0 || t >= n_tensors; };
+    for (int i = 0; i < n_convs; ++i) {
+        ConvSlot &c = net->convs[i];
+        c.d = convs[i];
+        const y3_conv_desc &d = c.d;
+        int err = 0;
+        if (bad_t(d.src0) || bad_t(d.dst) || (d.src1 >= 0 && bad_t(d.src1)) || (d.residual >= 0 && bad_t(d.residual))) err = 1;
+        if (!(d.size == 1 || d.size == 3) || !(d.stride == 1 || (d.stride == 2 && d.size == 3))) err = 2;
+        if (d.src1 >= 0 && (d.size != 1 || d.c0 % 32 || (d.cin - d.c0) % 32 || d.c0 <= 0 || d.c0 >= d.cin)) err = 3;
+        if (d.src1 < 0 && (d.c0 != d.cin || d.src0_upsample)) err = 4;
+        c.first_layer = (d.cin == 3);
+        if (c.first_layer && !(d.size == 3 && d.stride == 1 && d.cout == 32 && d.residual < 0 && d.src1 < 0)) err = 5;
+        if (!c.first_layer && d.cin % 32) err = 6;
+        if (d.cout <= 0 || d.out_div != d.in_div * d.stride) err = err ? err : 7;
+        if (err) {
+            delete net;
+            return fail(Y3_ERR_INVALID, "y3_net_create: conv %d unsupported or inconsistent (check %d)", i, err);
+        }
+        c.cout_pad = (d.cout + 31) / 32 * 32;
+        c.K = d.size * d.size * d.cin;
+    }
+    int ci = 0, ai = 0;
+    for (int i = 0; i < n_ops; ++i) {
+        if (op_kinds[i] == 0) {
+            if (ci >= n_convs) { delete net; return fail(Y3_ERR_INVALID, "y3_net_create: more conv ops than descriptors"); }
+            net->ops.push_back({0, ci++});
+        } else {
+            if (ai >= n_aux) { delete net; return fail(Y3_ERR_INVALID, "y3_net_create: more aux ops than descriptors"); }
+            net->ops.push_back({1, ai++});
+        }
+    }
+    if (bad_t(input_tensor)) { delete net; return fail(Y3_ERR_INVALID, "y3_net_create: bad input tensor"); }
+    net->input_tensor = input_tensor;
+    for (int i = 0; i < 3; ++i) {
+        // nclasses == 0: raw feature outputs (layer tests); otherwise the yolo head layout is enforced
+        if (bad_t(outputs[i]) || (nclasses > 0 && tensors[outputs[i]].channels != 3 * (5 + nclasses))) {
+            delete net;
+            return fail(Y3_ERR_INVALID, "y3_net_create: output %d must have 3*(5+nclasses) channels", i);
+        }
+        net->outputs[i] = outputs[i];
+    }
+    net->nclasses = nclasses;
+    net->tdev.assign(n_tensors, nullptr);
+    net->tbytes.assign(n_tensors, 0);
+    *out = net;
+    return Y3_OK;
+}
+
+void y3_net_destroy(y3_net *net)
+{
+    if (!net) return;
+    free_plan(net);
+    for (ConvSlot &c : net->convs) {
+        if (c.w_dev) (void)hipFree(c.w_dev);
+        if (c.scale_dev) (void)hipFree(c.scale_dev);
+        if (c.shift_dev) (void)hipFree(c.shift_dev);
+    }
+    delete net;
+}
+
+y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const float *gamma, const float *beta,
+                                  const float *mean, const float *var, const float *bias, float eps)
+{
+    if (!net || slot < 0 || slot >= (int)net->convs.size() || !w)
+        return fail(Y3_ERR_INVALID, "y3_net_set_conv_weights: bad slot or null weights");
+    ConvSlot &c = net->convs[slot];
+    const y3_conv_desc &d = c.d;
+    if (d.bn ? !(gamma && beta && mean && var) : !bias)
+        return fail(Y3_ERR_INVALID, "y3_net_set_conv_weights: conv %d needs %s", slot, d.bn ? "gamma/beta/mean/var" : "bias");
+    const int K = c.K, CP = c.cout_pad;
+    std::vector<float> scale(CP, 1.0f), shift(CP, 0.0f);
+    for (int n = 0; n < d.cout; ++n) {
+        if (d.bn) {
+            // BatchNormalization inference: y = x*scale + (beta - mean*scale), scale = gamma*rsqrt(var+eps)
+            const float inv = 1.0f / sqrtf(var[n] + eps);
+            scale[n] = inv * gamma[n];
+            shift[n] = beta[n] - mean[n] * scale[n];
+        } else {
+            shift[n] = bias[n];
+        }
+    }
+    std::vector<float> pk;
+    if (c.first_layer) {
+        pk.assign(w, w + (size_t)K * d.cout);  // HWIO as is
+    } else {
+        pk.assign((size_t)CP * K, 0.0f);       // [CoutPad][K], k = tap*Cin + c  (HWIO is [K][Cout])
+        for (int k = 0; k < K; ++k)
+            for (int n = 0; n < d.cout; ++n) pk[(size_t)n * K + k] = w[(size_t)k * d.cout + n];
+    }
+    HIP_TRY(hipSetDevice(net->device));
+    if (!c.w_dev) HIP_TRY(hipMalloc(&c.w_dev, pk.size() * sizeof(float)));
+    if (!c.scale_dev) HIP_TRY(hipMalloc(&c.scale_dev, CP * sizeof(float)));
+    if (!c.shift_dev) HIP_TRY(hipMalloc(&c.shift_dev, CP * sizeof(float)));
+    HIP_TRY(hipMemcpy(c.w_dev, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.scale_dev, scale.data(), CP * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.shift_dev, shift.data(), CP * sizeof(float), hipMemcpyHostToDevice));
+    c.loaded = true;
+    return Y3_OK;
+}
+
+y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
+{
+    if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::TILE_COUNT)
+        return fail(Y3_ERR_INVALID, "y3_net_set_tile: bad argument");
+    ConvSlot &c = net->convs[slot];
+    if (tile >= 0) {
+        y3::TileShape s = y3::conv_tile_shape(tile);
+        if (c.first_layer || c.cout_pad % s.bn) return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile does not divide Cout");
+    }
+    c.tile = tile;
+    return Y3_OK;
+}
+
+y3_status y3_net_keep_activations(y3_net *net, int keep)
+{
+    if (!net) return fail(Y3_ERR_INVALID, "y3_net_keep_activations: null net");
+    net->keep_all = keep ? 1 : 0;
+    return Y3_OK;
+}
+
+y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
+{
+    if (!net || max_batch <= 0 || image_size <= 0) return fail(Y3_ERR_INVALID, "y3_net_plan: bad argument");
+    if (dtype != Y3_DTYPE_F32) return fail(Y3_ERR_INVALID, "y3_net_plan: only Y3_DTYPE_F32 is implemented");
+    for (const y3_tensor_desc &t : net->tensors)
+        if (t.div <= 0 || image_size % t.div) return fail(Y3_ERR_INVALID, "y3_net_plan: image_size %d not divisible by %d", image_size, t.div);
+    HIP_TRY(hipSetDevice(net->device));
+    free_plan(net);
+    net->max_batch = max_batch;
+    net->image_size = image_size;
+    net->dtype = dtype;
+    const int nt = (int)net->tensors.size();
+    // liveness over the op list; tensors with equal lifetime class share blocks (first-fit free list)
+    std::vector<int> first(nt, -1), last(nt, -1);
+    auto touch = [&](int t, int i) {
+        if (t < 0) return;
+        if (first[t] < 0) first[t] = i;
+        last[t] = i;
+    };
+    for (int i = 0; i < (int)net->ops.size(); ++i) {
+        const Op &o = net->ops[i];
+        if (o.kind == 0) {
+            const y3_conv_desc &d = net->convs[o.index].d;
+            touch(d.src0, i); touch(d.src1, i); touch(d.residual, i); touch(d.dst, i);
+        } else {
+            const y3_aux_desc &a = net->aux[o.index];
+            touch(a.src0, i); touch(a.src1, i); touch(a.dst, i);
+        }
+    }
+    for (int t = 0; t < nt; ++t) {
+        const int s = image_size / net->tensors[t].div;
+        net->tbytes[t] = (size_t)max_batch * s * s * net->tensors[t].channels * sizeof(float);
+        if (net->tbytes[t] >= 0xFFFFFFF0ull && first[t] >= 0)
+            return fail(Y3_ERR_INVALID, "y3_net_plan: tensor %d is %zu bytes; 32-bit buffer offsets need < 4 GiB, lower max_batch", t, net->tbytes[t]);
+    }
+    struct Blk { void *p; size_t bytes; int free_at; };
+    std::vector<Blk> pool;
+    // allocate in order of first definition; the image batch and the head grids are caller-owned
+    std::vector<int> order;
+    for (int t = 0; t < nt; ++t) {
+        const bool external = (t == net->input_tensor || t == net->outputs[0] || t == net->outputs[1] || t == net->outputs[2]);
+        if (first[t] >= 0 && !external) order.push_back(t);
+    }
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
+    for (int t : order) {
+        const int until = net->keep_all ? (int)net->ops.size() + 1 : last[t];
+        int pick = -1;
+        for (int k = 0; k < (int)pool.size(); ++k)
+            if (pool[k].free_at < first[t] && pool[k].bytes >= net->tbytes[t] &&
+                (pick < 0 || pool[k].bytes < pool[pick].bytes))
+                pick = k;
+        if (pick < 0) {
+            void *p = nullptr;
+            hipError_t e = hipMalloc(&p, net->tbytes[t]);
+            if (e != hipSuccess) {
+                free_plan(net);
+                return fail(Y3_ERR_OOM, "y3_net_plan: hipMalloc(%zu) failed: %s", net->tbytes[t], hipGetErrorString(e));
+            }
+            net->blocks.push_back(p);
+            pool.push_back({p, net->tbytes[t], until});
+            pick = (int)pool.size() - 1;
+        }
+        pool[pick].free_at = until;
+        net->tdev[t] = pool[pick].p;
+    }
+    return Y3_OK;
+}
+
+double y3_net_flops_per_image(const y3_net *net)
+{
+    if (!net || !net->image_size) return 0.0;
+    double tot = 0;
+    for (const ConvSlot &c : net->convs) {
+        const double ho = net->image_size / c.d.out_div;
+        tot += 2.0 * c.d.size * c.d.size * c.d.cin * c.d.cout * ho * ho;
+    }
+    return tot;
+}
+
+static y3_status run(y3_net *net, const float *images, int batch, float *const grids[3], hipStream_t s,
+                     float *ms_out, int n_ms)
+{
+    if (!net || !images || !grids || batch <= 0) return fail(Y3_ERR_INVALID, "y3_net_forward: bad argument");
+    if (!net->image_size) return fail(Y3_ERR_STATE, "y3_net_forward: call y3_net_plan first");
+    if (batch > net->max_batch) return fail(Y3_ERR_INVALID, "y3_net_forward: batch %d > planned %d", batch, net->max_batch);
+    for (size_t i = 0; i < net->convs.size(); ++i)
+        if (!net->convs[i].loaded) return fail(Y3_ERR_STATE, "y3_net_forward: conv %zu has no weights", i);
+    for (int i = 0; i < 3; ++i)
+        if (!grids[i] || ((uintptr_t)grids[i] & 15)) return fail(Y3_ERR_INVALID, "y3_net_forward: grid %d null or not 16-byte aligned", i);
+    if ((uintptr_t)images & 3) return fail(Y3_ERR_INVALID, "y3_net_forward: images not 4-byte aligned");
+    auto ptr = [&](int t) -> void * {
+        if (t < 0) return nullptr;
+        if (t == net->input_tensor) return const_cast<float *>(images);
+        for (int i = 0; i < 3; ++i)
+            if (t == net->outputs[i]) return grids[i];
+        return net->tdev[t];
+    };
+    auto bytes = [&](int t) -> size_t {
+        const int sp = spatial(net, t);
+        return (size_t)batch * sp * sp * net->tensors[t].channels * sizeof(float);
+    };
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ms_out) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+    }
+    for (const Op &o : net->ops) {
+        if (o.kind == 0) {
+            ConvSlot &c = net->convs[o.index];
+            const y3_conv_desc &d = c.d;
+            y3::ConvArgs a{};
+            a.src0 = ptr(d.src0);
+            a.src1 = ptr(d.src1);
+            a.wpk = c.w_dev;
+            a.scale = c.scale_dev;
+            a.shift = c.shift_dev;
+            a.residual = ptr(d.residual);
+            a.dst = ptr(d.dst);
+            a.B = batch;
+            a.H = a.W = net->image_size / d.in_div;
+            a.Ho = a.Wo = net->image_size / d.out_div;
+            a.Cin = d.cin;
+            a.C0 = d.c0;
+            a.Cout = d.cout;
+            a.CoutPad = c.cout_pad;
+            a.ksize = d.size;
+            a.stride = d.stride;
+            a.pad = (d.size == 3) ? 1 : 0;
+            a.up0 = d.src0_upsample;
+            a.leaky = d.leaky;
+            a.M = batch * a.Ho * a.Wo;
+            a.K = c.K;
+            a.src0_bytes = (unsigned)bytes(d.src0);
+            a.src1_bytes = d.src1 >= 0 ? (unsigned)bytes(d.src1) : 0;
+            a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * sizeof(float));
+            if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
+            if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
+            hipError_t e;
+            if (c.first_layer) {
+                e = y3::launch_conv_first_f32(a, c.w_dev, s);
+            } else {
+                const int tile = c.tile >= 0 ? c.tile : choose_tile(c, a.M);
+                e = y3::launch_conv_f32(a, tile, s);
+            }
+            if (e != hipSuccess) return fail(Y3_ERR_HIP, "conv %d launch: %s", o.index, hipGetErrorString(e));
+            if (ms_out) {
+                HIP_TRY(hipEventRecord(ev1, s));
+                HIP_TRY(hipEventSynchronize(ev1));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+                if (o.index < n_ms) ms_out[o.index] = ms;
+            }
+        } else {
+            const y3_aux_desc &x = net->aux[o.index];
+            const int sp = spatial(net, x.dst);
+            const int C = net->tensors[x.dst].channels;
+            hipError_t e = hipSuccess;
+            if (x.kind == Y3_AUX_ADD)
+                e = y3::launch_add((const float *)ptr(x.src0), (const float *)ptr(x.src1), (float *)ptr(x.dst),
+                                   (size_t)batch * sp * sp * C, s);
+            else if (x.kind == Y3_AUX_UPSAMPLE2X)
+                e = y3::launch_upsample2x((const float *)ptr(x.src0), batch, sp / 2, sp / 2, C, (float *)ptr(x.dst), s);
+            else if (x.kind == Y3_AUX_CONCAT)
+                e = y3::launch_concat((const float *)ptr(x.src0), net->tensors[x.src0].channels,
+                                      (const float *)ptr(x.src1), net->tensors[x.src1].channels,
+                                      (size_t)batch * sp * sp, (float *)ptr(x.dst), s);
+            else
+                return fail(Y3_ERR_INVALID, "unknown aux op kind %d", x.kind);
+            if (e != hipSuccess) return fail(Y3_ERR_HIP, "aux op %d launch: %s", o.index, hipGetErrorString(e));
+        }
+    }
+    if (ms_out) {
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+    }
+    return Y3_OK;
+}
+
+y3_status y3_net_forward(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], void *stream)
+{
+    return run(net, images_dev, batch, grids_dev, (hipStream_t)stream, nullptr, 0);
+}
+
+y3_status y3_net_profile_convs(y3_net *net, const float *images_dev, int batch, float *ms_out, int n, void *stream)
+{
+    if (!net || !ms_out) return fail(Y3_ERR_INVALID, "y3_net_profile_convs: bad argument");
+    // head grids go to scratch owned by this call
+    float *g[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; ++i) {
+        const int sp = spatial(net, net->outputs[i]);
+        HIP_TRY(hipMalloc(&g[i], (size_t)batch * sp * sp * net->tensors[net->outputs[i]].channels * sizeof(float)));
+    }
+    y3_status st = run(net, images_dev, batch, g, (hipStream_t)stream, ms_out, n);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    for (int i = 0; i < 3; ++i) (void)hipFree(g[i]);
+    return st;
+}
+
+y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size_t *n_elems, void *stream)
+{
+    if (!net || t < 0 || t >= (int)net->tensors.size() || !net->image_size)
+        return fail(Y3_ERR_INVALID, "y3_net_read_tensor: bad argument");
+    const int sp = spatial(net, t);
+    const size_t n = (size_t)batch * sp * sp * net->tensors[t].channels;
+    if (n_elems) *n_elems = n;
+    if (!dst_dev) return Y3_OK;
+    if (!net->tdev[t]) return fail(Y3_ERR_STATE, "y3_net_read_tensor: tensor %d is not held in the arena", t);
+    HIP_TRY(hipMemcpyAsync(dst_dev, net->tdev[t], n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return Y3_OK;
+}
+
+// ------------------------------------------------------------------------------------------ decode
+static y3_status decode_common(const float *const grids[3], const int32_t gs[3], int batch, int nc,
+                               const float *anchors, float *bboxes, float *conf, float *probs, int64_t *cls,
+                               float *scores, void *stream, const char *who)
+{
+    if (!grids || !gs || !anchors || !bboxes || batch <= 0 || nc <= 0) return fail(Y3_ERR_INVALID, "%s: bad argument", who);
+    y3::DecodeArgs a{};
+    int off = 0;
+    for (int s = 0; s < 3; ++s) {
+        if (!grids[s] || gs[s] <= 0 || ((uintptr_t)grids[s] & 15))
+            return fail(Y3_ERR_INVALID, "%s: grid %d null, empty or not 16-byte aligned", who, s);
+        a.grid[s] = grids[s];
+        a.g[s] = gs[s];
+        a.off[s] = off;
+        off += gs[s] * gs[s] * 3;
+        for (int k = 0; k < 3; ++k) {
+            a.anchors[s][k][0] = anchors[(s * 3 + k) * 2 + 0];
+            a.anchors[s][k][1] = anchors[(s * 3 + k) * 2 + 1];
+        }
+    }
+    if ((uintptr_t)bboxes & 15) return fail(Y3_ERR_INVALID, "%s: bboxes not 16-byte aligned", who);
+    a.B = batch;
+    a.N = off;
+    a.nc = nc;
+    hipError_t e = y3::launch_decode(a, bboxes, conf, probs, cls, scores, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(Y3_ERR_HIP, "%s launch: %s", who, hipGetErrorString(e));
+    return Y3_OK;
+}
+
+y3_status y3_yolo_decode(const float *const grids_dev[3], const int32_t grid_sizes[3], int batch, int nclasses,
+                         const float *anchors_host, float *bboxes_dev, float *conf_dev, float *probs_dev, void *stream)
+{
+    if (!conf_dev || !probs_dev) return fail(Y3_ERR_INVALID, "y3_yolo_decode: null output");
+    return decode_common(grids_dev, grid_sizes, batch, nclasses, anchors_host, bboxes_dev, conf_dev, probs_dev, nullptr,
+                         nullptr, stream, "y3_yolo_decode");
+}
+
+y3_status y3_yolo_decode_scores(const float *const grids_dev[3], const int32_t grid_sizes[3], int batch, int nclasses,
+                                const float *anchors_host, float *bboxes_dev, int64_t *class_idx_dev,
+                                float *scores_dev, void *stream)
+{
+    if (!class_idx_dev || !scores_dev) return fail(Y3_ERR_INVALID, "y3_yolo_decode_scores: null output");
+    return decode_common(grids_dev, grid_sizes, batch, nclasses, anchors_host, bboxes_dev, nullptr, nullptr,
+                         class_idx_dev, scores_dev, stream, "y3_yolo_decode_scores");
+}
+
+y3_status y3_class_scores(const float *conf_dev, const float *probs_dev, int batch, int n, int nclasses,
+                          int64_t *class_idx_dev, float *scores_dev, void *stream)
+{
+    if (!conf_dev || !probs_dev || !class_idx_dev || !scores_dev || batch <= 0 || n <= 0 || nclasses <= 0)
+        return fail(Y3_ERR_INVALID, "y3_class_scores: bad argument");
+    hipError_t e = y3::launch_class_scores(conf_dev, probs_dev, (size_t)batch * n, nclasses, class_idx_dev, scores_dev,
+                                           (hipStream_t)stream);
+    if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_class_scores launch: %s", hipGetErrorString(e));
+    return Y3_OK;
+}
+
+// ------------------------------------------------------------------------------------------ nms
+size_t y3_nms_workspace_bytes(int batch, int n) { return (batch > 0 && n > 0) ? y3::nms_workspace_bytes(batch, n) : 0; }
+
+y3_status y3_nms_padded(const float *bboxes_dev, const float *scores_dev, int batch, int n, int max_output_size,
+                        float iou_threshold, float score_threshold, int32_t *selected_idx_dev,
+                        int32_t *num_valid_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
+{
+    if (!bboxes_dev || !scores_dev || !selected_idx_dev || !num_valid_dev || batch <= 0 || n <= 0)
+        return fail(Y3_ERR_INVALID, "y3_nms_padded: bad argument");
+    if (max_output_size <= 0 || max_output_size > 1024)
+        return fail(Y3_ERR_INVALID, "y3_nms_padded: max_output_size must be in [1,1024]");
+    if ((uintptr_t)bboxes_dev & 15) return fail(Y3_ERR_INVALID, "y3_nms_padded: bboxes not 16-byte aligned");
+    if (!workspace_dev || workspace_bytes < y3::nms_workspace_bytes(batch, n))
+        return fail(Y3_ERR_INVALID, "y3_nms_padded: workspace too small (need %zu bytes)", y3::nms_workspace_bytes(batch, n));
+    hipError_t e = y3::launch_nms(bboxes_dev, scores_dev, batch, n, max_output_size, iou_threshold, score_threshold,
+                                  selected_idx_dev, num_valid_dev, workspace_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_nms_padded launch: %s", hipGetErrorString(e));
+    return Y3_OK;
+}
+
+y3_status y3_pack_detections(const float *bboxes_dev, const int64_t *class_idx_dev, const float *scores_dev,
+                             const int32_t *selected_idx_dev, const int32_t *num_valid_dev, int batch, int n,
+                             int max_out, void *packed_dev, void *stream)
+{
+    if (!bboxes_dev || !class_idx_dev || !scores_dev || !selected_idx_dev || !num_valid_dev || !packed_dev ||
+        batch <= 0 || n <= 0 || max_out <= 0)
+        return fail(Y3_ERR_INVALID, "y3_pack_detections: bad argument");
+    hipError_t e = y3::launch_pack(bboxes_dev, class_idx_dev, scores_dev, selected_idx_dev, num_valid_dev, batch, n,
+                                   max_out, packed_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_pack_detections launch: %s", hipGetErrorString(e));
+    return Y3_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// Internal launch interface between the C-ABI layer (y3_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace y3 {
+
+// One fused conv launch: Conv2D [+BN] [+LeakyReLU(0.1)] [+shortcut add], optional
+// (nearest-x2-upsampled src0) (+) src1 channel concat in the A-operand gather.
+struct ConvArgs {
+    const void *src0;      // [B,H0,W0,C0]  (H0 = H/2 when up0)
+    const void *src1;      // [B,H,W,Cin-C0] or nullptr
+    const void *wpk;       // packed weights [CoutPad][K], K = taps*Cin, k = tap*Cin + c
+    const float *scale;    // [CoutPad] BN scale (1 for bias convs)
+    const float *shift;    // [CoutPad] BN shift / bias
+    const void *residual;  // [B,Ho,Wo,Cout] or nullptr
+    void *dst;             // [B,Ho,Wo,Cout]
+    int B, H, W;           // logical input spatial size
+    int Ho, Wo;
+    int Cin, C0;
+    int Cout, CoutPad;
+    int ksize, stride, pad;
+    int up0;
+    int leaky;
+    int M;                 // B*Ho*Wo
+    int K;                 // ksize*ksize*Cin
+    unsigned src0_bytes, src1_bytes, w_bytes;
+};
+
+// tile configurations of the fp32 MFMA kernel (index into the dispatch table)
+enum ConvTile { TILE_128x128 = 0, TILE_256x64, TILE_256x32, TILE_128x64, TILE_64x128, TILE_64x64, TILE_COUNT };
+struct TileShape { int bm, bn; };
+TileShape conv_tile_shape(int tile);
+
+hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
+// first layer: 3x3 stride-1 conv with Cin=3 (direct, VALU)
+hipError_t launch_conv_first_f32(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
+
+hipError_t launch_add(const float *a, const float *b, float *y, size_t n, hipStream_t s);
+hipError_t launch_upsample2x(const float *x, int B, int H, int W, int C, float *y, hipStream_t s);
+hipError_t launch_concat(const float *a, int Ca, const float *b, int Cb, size_t npix, float *y, hipStream_t s);
+
+struct DecodeArgs {
+    const float *grid[3];
+    int g[3];
+    int off[3];     // first box index of each scale
+    float anchors[3][3][2];
+    int B, N, nc;
+};
+hipError_t launch_decode(const DecodeArgs &a, float *bboxes, float *conf, float *probs, int64_t *cls,
+                         float *scores, hipStream_t s);
+hipError_t launch_class_scores(const float *conf, const float *probs, size_t n, int nc, int64_t *cls,
+                               float *scores, hipStream_t s);
+
+size_t nms_workspace_bytes(int B, int N);
+hipError_t launch_nms(const float *boxes, const float *scores, int B, int N, int M, float T, float S, int32_t *sel,
+                      int32_t *num_valid, void *ws, hipStream_t s);
+hipError_t launch_pack(const float *boxes, const int64_t *cls, const float *scores, const int32_t *sel,
+                       const int32_t *nv, int B, int N, int M, void *packed, hipStream_t s);
+
+}  // namespace y3

@@ -1,0 +1,254 @@
+"""Thin host wrappers around the C ABI: torch tensors in, torch tensors out.
+
+PyTorch is used for device memory and streams only; every arithmetic step below is a call into
+liby3hip.so on the current torch stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AuxDesc, ConvDesc, TensorDesc, Y3Error, check
+from .graph import AuxOp, ConvOp, Program
+from .weights import BN_EPS
+
+_AUX_KIND = {"add": _lib.Y3_AUX_ADD, "upsample": _lib.Y3_AUX_UPSAMPLE2X, "concat": _lib.Y3_AUX_CONCAT}
+
+
+def _fptr(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dev(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or not t.is_contiguous()):
+            raise Y3Error("expected contiguous CUDA(HIP) tensors; the y3 kernels have no CPU fallback")
+
+
+class Net:
+    """Device-side network = the fused conv program (reference counterpart: the Keras Model returned by
+    ParseModel.build_model, core/parse_model.py:279-314)."""
+
+    def __init__(self, program: Program):
+        _lib.require_gpu()
+        self.program = program
+        self.lib = _lib.load()
+        p = program
+        tens = (TensorDesc * len(p.tensors))(*[TensorDesc(t.channels, t.div) for t in p.tensors])
+        kinds, convs, auxs = [], [], []
+        self.conv_ops: List[ConvOp] = []
+        for o in p.ops:
+            if isinstance(o, ConvOp):
+                kinds.append(0)
+                convs.append(ConvDesc(o.size, o.stride, o.cin, o.cout, int(o.bn), int(o.leaky), o.src0,
+                                      int(o.src0_upsample), o.c0, o.src1, o.residual, o.dst, o.in_div, o.out_div))
+                self.conv_ops.append(o)
+            elif isinstance(o, AuxOp):
+                kinds.append(1)
+                auxs.append(AuxDesc(_AUX_KIND[o.kind], o.inputs[0], o.inputs[1] if len(o.inputs) > 1 else -1, o.dst))
+        if len(p.outputs) != 3:
+            raise Y3Error("the HIP path expects exactly three detection heads")
+        self._h = C.c_void_p()
+        k_arr = (C.c_int32 * len(kinds))(*kinds)
+        c_arr = (ConvDesc * max(1, len(convs)))(*convs)
+        a_arr = (AuxDesc * max(1, len(auxs)))(*auxs)
+        outs = (C.c_int32 * 3)(*p.outputs)
+        check(self.lib.y3_net_create(tens, len(p.tensors), k_arr, len(kinds), c_arr, len(convs), a_arr, len(auxs),
+                                     p.input_tensor, outs, p.nclasses, C.byref(self._h)), "y3_net_create")
+        self.image_size = 0
+        self.max_batch = 0
+        self.weights_loaded = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self.lib.y3_net_destroy(h)
+            self._h = C.c_void_p()
+
+    # -- weights ----------------------------------------------------------------------------------
+    def load_weights(self, weights: Dict[str, np.ndarray], eps: float = BN_EPS):
+        for slot, o in enumerate(self.conv_ops):
+            i = o.conv_index
+            w = np.ascontiguousarray(weights[f"conv{i}.w"], np.float32)
+            if w.shape != (o.size, o.size, o.cin, o.cout):
+                raise Y3Error(f"conv{i}.w has shape {w.shape}, expected {(o.size, o.size, o.cin, o.cout)}")
+            get = lambda k: np.ascontiguousarray(weights[f"conv{i}.{k}"], np.float32)
+            if o.bn:
+                g, b, m, v = get("gamma"), get("beta"), get("mean"), get("var")
+                st = self.lib.y3_net_set_conv_weights(self._h, slot, _fptr(w), _fptr(g), _fptr(b), _fptr(m), _fptr(v),
+                                                      None, eps)
+            else:
+                bias = get("bias")
+                st = self.lib.y3_net_set_conv_weights(self._h, slot, _fptr(w), None, None, None, None, _fptr(bias), eps)
+            check(st, f"y3_net_set_conv_weights(conv{i})")
+        self.weights_loaded = True
+
+    # -- planning / execution ---------------------------------------------------------------------
+    def keep_activations(self, keep=True):
+        check(self.lib.y3_net_keep_activations(self._h, int(keep)), "y3_net_keep_activations")
+
+    def set_tile(self, slot: int, tile: int):
+        check(self.lib.y3_net_set_tile(self._h, slot, tile), "y3_net_set_tile")
+
+    def plan(self, max_batch: int, image_size: int, dtype: int = _lib.Y3_DTYPE_F32):
+        check(self.lib.y3_net_plan(self._h, max_batch, image_size, dtype), "y3_net_plan")
+        self.max_batch, self.image_size = max_batch, image_size
+
+    def grid_sizes(self, image_size=None):
+        s = image_size or self.image_size
+        return [s // self.program.tensors[o].div for o in self.program.outputs]
+
+    def forward(self, images: torch.Tensor, out: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
+        """images [B,S,S,3] fp32 on the GPU -> [grid13, grid26, grid52], each [B,g,g,3,5+nc]."""
+        _need_cuda(images)
+        cin = self.program.tensors[self.program.input_tensor].channels
+        if images.dtype != torch.float32 or images.dim() != 4 or images.shape[3] != cin or images.shape[1] != images.shape[2]:
+            raise Y3Error(f"images must be float32 [B,S,S,{cin}]")
+        B, S = images.shape[0], images.shape[1]
+        if S != self.image_size or B > self.max_batch:
+            self.plan(max(B, self.max_batch), S)
+        nc = self.program.nclasses
+        gs = self.grid_sizes()
+        if out is None:
+            if nc > 0:
+                out = [torch.empty((B, g, g, 3, 5 + nc), dtype=torch.float32, device=images.device) for g in gs]
+            else:  # raw feature outputs (layer tests)
+                out = [torch.empty((B, g, g, self.program.tensors[o].channels), dtype=torch.float32,
+                                   device=images.device) for g, o in zip(gs, self.program.outputs)]
+        _need_cuda(*out)
+        ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in out])
+        check(self.lib.y3_net_forward(self._h, _dev(images), B, ptrs, _lib.stream_ptr()), "y3_net_forward")
+        return list(out)
+
+    __call__ = forward
+
+    def read_tensor(self, tensor_id: int, batch: int) -> torch.Tensor:
+        n = C.c_size_t()
+        check(self.lib.y3_net_read_tensor(self._h, tensor_id, batch, None, C.byref(n), None), "y3_net_read_tensor")
+        t = self.program.tensors[tensor_id]
+        s = self.image_size // t.div
+        out = torch.empty((batch, s, s, t.channels), dtype=torch.float32, device="cuda")
+        assert out.numel() == n.value
+        check(self.lib.y3_net_read_tensor(self._h, tensor_id, batch, _dev(out), C.byref(n), _lib.stream_ptr()),
+              "y3_net_read_tensor")
+        return out
+
+    def flops_per_image(self) -> float:
+        return float(self.lib.y3_net_flops_per_image(self._h))
+
+    def profile_convs(self, images: torch.Tensor) -> np.ndarray:
+        _need_cuda(images)
+        ms = np.zeros(len(self.conv_ops), np.float32)
+        check(self.lib.y3_net_profile_convs(self._h, _dev(images), images.shape[0], _fptr(ms), len(ms),
+                                            _lib.stream_ptr()), "y3_net_profile_convs")
+        return ms
+
+
+# ------------------------------------------------------------------------------------------------
+def _grids_args(grids):
+    _need_cuda(*grids)
+    if len(grids) != 3:
+        raise Y3Error("expected three grids")
+    for g in grids:
+        if g.dtype != torch.float32 or g.dim() != 5 or g.shape[1] != g.shape[2] or g.shape[3] != 3:
+            raise Y3Error("each grid must be float32 [B,g,g,3,5+nc]")
+    ptrs = (C.c_void_p * 3)(*[g.data_ptr() for g in grids])
+    gs = (C.c_int32 * 3)(*[g.shape[1] for g in grids])
+    B = grids[0].shape[0]
+    N = sum(3 * g.shape[1] * g.shape[2] for g in grids)
+    return ptrs, gs, B, N
+
+
+def _anchors(anchors_table):
+    a = np.ascontiguousarray(anchors_table.detach().cpu().numpy() if isinstance(anchors_table, torch.Tensor)
+                             else anchors_table, np.float32)
+    if a.shape != (3, 3, 2):
+        raise Y3Error("anchors_table must be [3,3,2]")
+    return a
+
+
+def yolo_decode(grids, anchors_table, nclasses):
+    """-> (bboxes [B,N,4], confidence [B,N,1], class_probs [B,N,nc])"""
+    ptrs, gs, B, N = _grids_args(grids)
+    a = _anchors(anchors_table)
+    dev = grids[0].device
+    bboxes = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+    conf = torch.empty((B, N, 1), dtype=torch.float32, device=dev)
+    probs = torch.empty((B, N, nclasses), dtype=torch.float32, device=dev)
+    check(_lib.load().y3_yolo_decode(ptrs, gs, B, nclasses, _fptr(a), _dev(bboxes), _dev(conf), _dev(probs),
+                                     _lib.stream_ptr()), "y3_yolo_decode")
+    return bboxes, conf, probs
+
+
+def yolo_decode_scores(grids, anchors_table, nclasses):
+    """fused decode + class arg-max/score -> (bboxes [B,N,4], class_indices [B,N] i64, scores [B,N])"""
+    ptrs, gs, B, N = _grids_args(grids)
+    a = _anchors(anchors_table)
+    dev = grids[0].device
+    bboxes = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, N), dtype=torch.int64, device=dev)
+    scores = torch.empty((B, N), dtype=torch.float32, device=dev)
+    check(_lib.load().y3_yolo_decode_scores(ptrs, gs, B, nclasses, _fptr(a), _dev(bboxes), _dev(cls), _dev(scores),
+                                            _lib.stream_ptr()), "y3_yolo_decode_scores")
+    return bboxes, cls, scores
+
+
+def class_scores(conf, probs):
+    _need_cuda(conf, probs)
+    B, N, nc = probs.shape
+    cls = torch.empty((B, N), dtype=torch.int64, device=probs.device)
+    scores = torch.empty((B, N), dtype=torch.float32, device=probs.device)
+    check(_lib.load().y3_class_scores(_dev(conf), _dev(probs), B, N, nc, _dev(cls), _dev(scores), _lib.stream_ptr()),
+          "y3_class_scores")
+    return cls, scores
+
+
+_ws_cache: Dict[tuple, torch.Tensor] = {}
+
+
+def nms_padded(bboxes, scores, max_output_size, iou_threshold, score_threshold):
+    """-> (selected_indices_padded [B,M] i32, num_valid [B] i32)"""
+    _need_cuda(bboxes, scores)
+    if bboxes.dtype != torch.float32 or scores.dtype != torch.float32:
+        raise Y3Error("boxes and scores must be float32")
+    B, N = scores.shape
+    lib = _lib.load()
+    need = lib.y3_nms_workspace_bytes(B, N)
+    key = (bboxes.device.index, need)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        _ws_cache.clear()
+        ws = _ws_cache[key] = torch.empty(need, dtype=torch.uint8, device=bboxes.device)
+    sel = torch.empty((B, int(max_output_size)), dtype=torch.int32, device=bboxes.device)
+    nv = torch.empty((B,), dtype=torch.int32, device=bboxes.device)
+    check(lib.y3_nms_padded(_dev(bboxes), _dev(scores), B, N, int(max_output_size), float(iou_threshold),
+                            float(score_threshold), _dev(sel), _dev(nv), _dev(ws), need, _lib.stream_ptr()),
+          "y3_nms_padded")
+    return sel, nv
+
+
+def pack_detections(bboxes, cls, scores, sel, nv):
+    """-> [B,M,7] int32 words: box (4 x f32 bits), score (f32 bits), class, index; rows >= num_valid zero"""
+    _need_cuda(bboxes, cls, scores, sel, nv)
+    B, N = scores.shape
+    M = sel.shape[1]
+    out = torch.empty((B, M, 7), dtype=torch.int32, device=bboxes.device)
+    check(_lib.load().y3_pack_detections(_dev(bboxes), _dev(cls), _dev(scores), _dev(sel), _dev(nv), B, N, M, _dev(out),
+                                         _lib.stream_ptr()), "y3_pack_detections")
+    return out
+
+
+def unpack_detections(packed: torch.Tensor):
+    """[.., M, 7] int32 words -> (boxes f32 [..,M,4], scores f32 [..,M], classes i32, indices i32)"""
+    f = packed[..., :5].contiguous().view(torch.float32)
+    return f[..., :4], f[..., 4], packed[..., 5], packed[..., 6]
