@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel trace stats + PMC passes) into per-kernel summaries."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"conv_f32_mfmaILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d)", name)
+    if m:
+        tm, tn, wr, wc, cat, st = map(int, m.groups())
+        return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{st}{',cat' if cat else ''}>"
+    for k in ("conv_first_f32", "decode_kernel", "nms_kernel", "pack_kernel", "class_scores"):
+        if k in name:
+            return k
+    return name[:60]
+
+
+def main(out):
+    # kernel stats
+    for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        with open(os.path.join(out, "summary_kernel_stats.txt"), "w") as o:
+            o.write(f"# rocprofv3 --kernel-trace --stats ({os.path.basename(f)})\n")
+            o.write(f"{'kernel':<52s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}\n")
+            for r in rows:
+                o.write(f"{short(r['Name']):<52s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} "
+                        f"{float(r['AverageNs'])/1e3:10.2f} {float(r['MinNs'])/1e3:10.2f} {float(r['MaxNs'])/1e3:10.2f} "
+                        f"{float(r['Percentage']):6.2f}\n")
+    # PMC passes: sum counters per kernel name
+    agg = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(int)
+    for p in sorted(glob.glob(os.path.join(out, "pmc*"))):
+        if not os.path.isdir(p):
+            continue
+        seen = set()
+        for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                key = (p, r["Dispatch_Id"])
+                if p.endswith("pmc1") and key not in seen:
+                    seen.add(key)
+                    calls[k] += 1
+    if agg:
+        names = sorted({c for k in agg for c in agg[k]})
+        with open(os.path.join(out, "summary_pmc.txt"), "w") as o:
+            o.write("# rocprofv3 --pmc, counter values summed over all dispatches of each kernel (and over XCDs/SEs)\n")
+            for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0)):
+                o.write(f"{k}  dispatches={calls[k]}\n")
+                for c in names:
+                    if c in agg[k]:
+                        o.write(f"    {c:<34s} {agg[k][c]:.6g}\n")
+    for f in ("summary_kernel_stats.txt", "summary_pmc.txt"):
+        fp = os.path.join(out, f)
+        if os.path.exists(fp):
+            print(open(fp).read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

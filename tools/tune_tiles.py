@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Per-conv tile sweep on the real network (GPU).  Times every conv launch (hipEvents inside
+y3_net_profile_convs) for every legal tile id and prints the table; --write stores the winners in
+yolo-v3-tf2_amd/tuning/<name>.json keyed by the conv's shape signature."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import yolo_v3_tf2_amd  # noqa: E402
+from yolo_v3_tf2_amd import runtime  # noqa: E402
+from yolo_v3_tf2_amd._lib import TILE_NAMES, TILES  # noqa: E402
+from yolo_v3_tf2_amd.graph import load_program  # noqa: E402
+from yolo_v3_tf2_amd.weights import synthetic_weights  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--image-size", type=int, default=416)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--tiles", type=str, default=",".join(str(i) for i in range(len(TILES))))
+    ap.add_argument("--write", type=str, default="")
+    a = ap.parse_args()
+    B, S = a.batch, a.image_size
+    p = load_program(os.path.join(ROOT, "config/models/yolov3/model.yaml"), 80)
+    w = synthetic_weights(p)
+    net = runtime.Net(p)
+    net.load_weights(w)
+    net.plan(B, S)
+    x = torch.rand((B, S, S, 3), device="cuda")
+    tiles = [int(t) for t in a.tiles.split(",")]
+    res = {}
+    for t in [-1] + tiles:
+        bn = TILES[t][1] if t >= 0 else 0
+        ok = []
+        for slot, o in enumerate(net.conv_ops):
+            cp = (o.cout + 31) // 32 * 32
+            legal = t < 0 or (o.cin != 3 and cp % bn == 0 and not (t >= 20 and o.src1 >= 0))
+            ok.append(legal)
+            net.set_tile(slot, t if legal else -1)
+        best = None
+        for _ in range(a.reps):
+            ms = net.profile_convs(x)
+            best = ms if best is None else np.minimum(best, ms)
+        res[t] = (best, ok)
+    names = {-1: "heur"}
+    names.update({t: TILE_NAMES[t] for t in tiles})
+    print("conv  shape                      " + " ".join(f"{names[t]:>11s}" for t in res))
+    winners = {}
+    tot_best = tot_heur = 0.0
+    for slot, o in enumerate(net.conv_ops):
+        ho = S // o.out_div
+        fl = 2.0 * o.size ** 2 * o.cin * o.cout * ho * ho * B
+        row = []
+        bt, bms = -1, res[-1][0][slot]
+        for t in res:
+            ms, ok = res[t]
+            if ok[slot]:
+                row.append(f"{fl / ms[slot] / 1e9:11.1f}")
+                if t >= 0 and ms[slot] < bms * 0.995:
+                    bt, bms = t, ms[slot]
+            else:
+                row.append("          -")
+        sig = f"k{o.size}s{o.stride}_c{o.cin}_n{o.cout}_h{ho}_r{int(o.residual >= 0)}_u{int(o.src1 >= 0)}"
+        winners[sig] = bt
+        tot_best += bms
+        tot_heur += res[-1][0][slot]
+        print(f"{o.conv_index:<4d}  {sig:<26s} " + " ".join(row) + f"   best={names.get(bt, 'heur')}")
+    print(f"sum heuristic {tot_heur:.3f} ms   sum best {tot_best:.3f} ms   "
+          f"({net.flops_per_image() * B / tot_best / 1e9:.1f} TF/s)")
+    if a.write:
+        d = os.path.join(ROOT, "yolo-v3-tf2_amd", "tuning")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, a.write), "w") as f:
+            json.dump({"batch": B, "image_size": S, "tiles": winners}, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

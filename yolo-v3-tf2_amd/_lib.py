@@ -16,7 +16,14 @@ LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "liby3hip.so")
 Y3_OK = 0
 Y3_DTYPE_F32, Y3_DTYPE_BF16 = 0, 1
 Y3_AUX_ADD, Y3_AUX_UPSAMPLE2X, Y3_AUX_CONCAT = 0, 1, 2
-TILE_NAMES = ["128x128", "256x64", "256x32", "128x64", "64x128", "64x64"]
+# (BM, BN, waves, LDS stages) of every tile id of the fp32 MFMA conv kernel (mirror of kTiles in csrc/conv_f32.hip)
+TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (64, 128, 4, 2), (64, 64, 4, 2),
+         (128, 128, 4, 1), (256, 64, 4, 1), (256, 32, 4, 1), (128, 64, 4, 1), (64, 128, 4, 1), (64, 64, 4, 1),
+         (128, 128, 8, 1), (128, 128, 8, 2), (128, 128, 16, 1), (128, 128, 16, 2),
+         (256, 128, 16, 1), (128, 64, 8, 1), (256, 64, 8, 1), (128, 64, 8, 2),
+         (64, 128, 4, 1), (64, 128, 4, 1), (64, 128, 4, 1)]  # 20..22: timing-only probes (wrong results)
+N_REAL_TILES = 20
+TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" for bm, bn, w, st in TILES]
 
 
 class Y3Error(RuntimeError):
@@ -74,6 +81,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise Y3Error(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
                           f"(or yolo-v3-tf2_amd/csrc/build.py); there is no CPU fallback")
+        import torch  # noqa: F401  -- first, so that torch's bundled HIP runtime (same soname) is the one we share
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares

@@ -7,7 +7,7 @@
 // GEMM view: M = B*Ho*Wo output pixels (NHWC order), N = Cout, K = taps*Cin with k = tap*Cin + c.
 //   A[m][k]  = input pixel (ho*s-pad+u, wo*s-pad+v) channel c, gathered on the fly (zero outside)
 //   B[n][k]  = packed weights [CoutPad][K]
-// Block tile BM x BN x 32, 256 threads = 4 waves (one per SIMD), wave tile (32*TM) x (32*TN).
+// Block tile BM x BN x 32, WR x WC waves (64*WR*WC threads), wave tile (32*TM) x (32*TN).
 // Both operand tiles live in LDS as [rows][32+4] floats (K contiguous, one 16-B pad per row:
 // row stride 9 x 16 B makes every ds_read_b128 of 16 different rows conflict-free), filled with
 // 16-B buffer loads -> ds_write_b128 and double buffered (one barrier per K tile).
@@ -27,20 +27,26 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int BK = 32;
 static constexpr int LDS_ROW = BK + 4;  // floats
 
-__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff)
+// 16-byte buffer load: per-lane voffset (range-checked against num_records) + wave-uniform soffset
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
 {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
     return __builtin_bit_cast(f32x4, v);
 }
 
-template <int TM, int TN, int WR, int WC, bool CONCAT>
-__global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
+// PROBE != 0 builds timing-only ablations of the main loop (wrong results; tools/tune_tiles.py --probe):
+//   1: LDS fragment reads + MFMA only   2: 1 + the two barriers   3: 2 + global fetches (never staged)
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0>
+__global__ __launch_bounds__(64 * WR * WC) void conv_f32_mfma(const ConvArgs p)
 {
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
-    constexpr int AP = BM / 32;  // A load passes (32 rows x 8 lanes of 16 B per pass)
-    constexpr int BP = BN / 32;
-    constexpr int STAGE = (BM + BN) * LDS_ROW;
+    constexpr int NT = 64 * WR * WC;
+    constexpr int RP = NT / 8;   // rows per load pass (8 lanes x 16 B cover one 32-float row)
+    constexpr int AP = BM / RP;  // A load passes
+    constexpr int BP = BN / RP;
+    static_assert(BM % RP == 0 && BN % RP == 0 && AP >= 1 && BP >= 1, "tile too small for the thread count");
+    constexpr int STAGE = (BM + BN) * LDS_ROW;  // floats per LDS stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
     const int C1 = p.Cin - p.C0;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int m = m0 + i * 32 + lrow;
+        const int m = m0 + i * RP + lrow;
         int b = m / HoWo;
         int r = m - b * HoWo;
         int ho = r / p.Wo;
@@ -98,19 +104,21 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
     }
     unsigned boff[BP];  // byte offset of this lane's piece of weight row n, k = 0
 #pragma unroll
-    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * 32 + lrow) * p.K + lchunk) * 4);
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * RP + lrow) * p.K + lchunk) * 4);
 
-    // walking state of the *next* K tile to fetch
+    // walking state of the *next* K tile to fetch.  The fp32 MFMA does not co-execute with VALU work
+    // (SQ_VALU_MFMA_COEXEC_CYCLES == 0 in the profile), so the K loop must issue (almost) no vector ALU
+    // instructions: per-lane byte offsets are fixed per tap (out-of-image lanes hold the out-of-range
+    // sentinel) and everything that changes per K tile goes into the scalar soffset of the buffer load.
     int tap = 0, c0 = 0;
-    unsigned avoff[AP];  // byte offset for the current tap
-    unsigned amask = 0;  // bit i: row i of this tap lies inside the image (and m < M)
+    unsigned avoff[AP];                  // voffset of this lane's piece for the current tap (or OOB0)
+    unsigned avoff1[CONCAT ? AP : 1];    // CONCAT: same for src1
     auto set_tap = [&]() {
-        amask = 0;
         if (CONCAT) {
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
-                avoff[i] = (unsigned)((aoff[i] + lchunk) * 4);
-                amask |= (ahw[i] < 0 ? 0u : 1u) << i;
+                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)((aoff[i] + lchunk) * 4);
+                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)((aoff1[i] + lchunk) * 4);
             }
         } else {
             const int u = tap / p.ksize, v = tap - u * p.ksize;
@@ -119,8 +127,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
             for (int i = 0; i < AP; ++i) {
                 const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
                 const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                avoff[i] = (unsigned)((aoff[i] + toff) * 4);
-                amask |= (ok ? 1u : 0u) << i;
+                avoff[i] = ok ? (unsigned)((aoff[i] + toff) * 4) : OOB0;
             }
         }
     };
@@ -133,18 +140,17 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
             // channels [0,C0) come from src0, [C0,Cin) from src1; a 32-wide K tile never straddles (C0 % 32 == 0)
             if (c0 < p.C0) {
 #pragma unroll
-                for (int i = 0; i < AP; ++i) ra[i] = buf_load16(rs0, (amask >> i) & 1 ? avoff[i] + c0 * 4 : OOB0);
+                for (int i = 0; i < AP; ++i) ra[i] = buf_load16(rs0, avoff[i], c0 * 4);
             } else {
 #pragma unroll
-                for (int i = 0; i < AP; ++i)
-                    ra[i] = buf_load16(rs1, (amask >> i) & 1 ? (unsigned)((aoff1[i] + lchunk + (c0 - p.C0)) * 4) : OOB1);
+                for (int i = 0; i < AP; ++i) ra[i] = buf_load16(rs1, avoff1[i], (c0 - p.C0) * 4);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < AP; ++i) ra[i] = buf_load16(rs0, (amask >> i) & 1 ? avoff[i] + c0 * 4 : OOB0);
+            for (int i = 0; i < AP; ++i) ra[i] = buf_load16(rs0, avoff[i], c0 * 4);
         }
 #pragma unroll
-        for (int j = 0; j < BP; ++j) rb[j] = buf_load16(rsw, boff[j] + kglob * 4);
+        for (int j = 0; j < BP; ++j) rb[j] = buf_load16(rsw, boff[j], kglob * 4);
         kglob += BK;
         c0 += BK;
         if (c0 == p.Cin) {
@@ -157,9 +163,9 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
         float *sa = smem + buf * STAGE;
         float *sb = sa + BM * LDS_ROW;
 #pragma unroll
-        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4 *>(sa + (i * 32 + lrow) * LDS_ROW + lchunk) = ra[i];
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4 *>(sa + (i * RP + lrow) * LDS_ROW + lchunk) = ra[i];
 #pragma unroll
-        for (int j = 0; j < BP; ++j) *reinterpret_cast<f32x4 *>(sb + (j * 32 + lrow) * LDS_ROW + lchunk) = rb[j];
+        for (int j = 0; j < BP; ++j) *reinterpret_cast<f32x4 *>(sb + (j * RP + lrow) * LDS_ROW + lchunk) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -180,8 +186,10 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
     const int b_frag = BM * LDS_ROW + (wc * 32 * TN + fr) * LDS_ROW + fh * 4;
 
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) fetch();
+        const int cur = (STAGES == 2) ? (kt & 1) : 0;
+        if (PROBE == 0 || PROBE == 3) {
+            if (kt + 1 < KT) fetch();
+        }
         const float *sa = smem + cur * STAGE + a_frag;
         const float *sb = smem + cur * STAGE + b_frag;
 #pragma unroll
@@ -199,14 +207,35 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) stage(cur ^ 1);
-        __syncthreads();
+        if (PROBE != 0) {
+            if (PROBE >= 2) {
+                __syncthreads();
+                __syncthreads();
+            }
+            if (PROBE == 3) {
+#pragma unroll
+                for (int i = 0; i < AP; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+                for (int j = 0; j < BP; ++j) asm volatile("" ::"v"(rb[j]));
+            }
+        } else if (STAGES == 2) {
+            if (kt + 1 < KT) stage(cur ^ 1);
+            __syncthreads();
+        } else if (kt + 1 < KT) {
+            __syncthreads();  // every wave is done reading the tile
+            stage(0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
-    // accumulator element e of lane l: column (n) = l & 31, row (m) = (e & 3) + 8*(e >> 2) + 4*(l >> 5)
-    float *dst = static_cast<float *>(p.dst);
-    const float *res = static_cast<const float *>(p.residual);
+    // accumulator element e of lane l: column (n) = l & 31, row (m) = (e & 3) + 8*(e >> 2) + 4*(l >> 5).
+    // Straight-line: out-of-tile elements get a voffset == num_records, which the buffer bounds check
+    // turns into "load 0 / drop the store"; the 16 residual loads of a sub-tile are issued together.
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(p.residual ? p.residual : p.dst), 0, p.dst_bytes, 0x00020000);
+    const bool has_res = p.residual != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wc * TN + j) * 32 + fr;
@@ -215,65 +244,84 @@ __global__ __launch_bounds__(256) void conv_f32_mfma(const ConvArgs p)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mbase = m0 + (wr * TM + i) * 32 + 4 * fh;
+            unsigned off[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mbase + (e & 3) + 8 * (e >> 2);
-                if (n_ok && m < p.M) {
-                    float v = acc[i][j][e] * sc + sh;
-                    if (p.leaky) v = (v >= 0.0f) ? v : 0.1f * v;
-                    const size_t o = (size_t)m * p.Cout + n;
-                    if (res) v = res[o] + v;
-                    dst[o] = v;
-                }
+                off[e] = (n_ok && m < p.M) ? (unsigned)(m * p.Cout + n) * 4u : p.dst_bytes;
+            }
+            float r[16];
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    r[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)off[e], 0, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] * sc + sh;
+                if (p.leaky) v = (v >= 0.0f) ? v : 0.1f * v;
+                if (has_res) v = r[e] + v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, (int)off[e], 0, 0);
             }
         }
     }
 }
 
-TileShape conv_tile_shape(int tile)
-{
-    switch (tile) {
-        case TILE_128x128: return {128, 128};
-        case TILE_256x64: return {256, 64};
-        case TILE_256x32: return {256, 32};
-        case TILE_128x64: return {128, 64};
-        case TILE_64x128: return {64, 128};
-        default: return {64, 64};
-    }
-}
+// tile table: {BM, BN, waves, LDS stages}; ids are stable (tuning files refer to them)
+static const TileInfo kTiles[TILE_COUNT] = {
+    {128, 128, 4, 2}, {256, 64, 4, 2}, {256, 32, 4, 2}, {128, 64, 4, 2}, {64, 128, 4, 2}, {64, 64, 4, 2},
+    {128, 128, 4, 1}, {256, 64, 4, 1}, {256, 32, 4, 1}, {128, 64, 4, 1}, {64, 128, 4, 1}, {64, 64, 4, 1},
+    {128, 128, 8, 1}, {128, 128, 8, 2}, {128, 128, 16, 1}, {128, 128, 16, 2},
+    {256, 128, 16, 1}, {128, 64, 8, 1}, {256, 64, 8, 1}, {128, 64, 8, 2},
+    {64, 128, 4, 1}, {64, 128, 4, 1}, {64, 128, 4, 1},  // timing-only probes of tile 10 (wrong results)
+};
 
-template <int TM, int TN, int WR, int WC>
-static hipError_t launch_t(const ConvArgs &a, hipStream_t s)
+TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUNT) ? tile : 0]; }
+
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0>
+static hipError_t launch_k(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
-    const size_t lds = 2 * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
-    dim3 grid(tilesM * tilesN), block(256);
-    if (a.src1) {
-        auto k = conv_f32_mfma<TM, TN, WR, WC, true>;
+    const size_t lds = STAGES * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
+    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds, s, a);
-    } else {
-        auto k = conv_f32_mfma<TM, TN, WR, WC, false>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, grid, block, lds, s, a);
+        attr_set = true;
     }
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
+}
+
+template <int TM, int TN, int WR, int WC>
+static hipError_t launch_t(const ConvArgs &a, int stages, hipStream_t s)
+{
+    if (a.src1) return stages == 2 ? launch_k<TM, TN, WR, WC, true, 2>(a, s) : launch_k<TM, TN, WR, WC, true, 1>(a, s);
+    return stages == 2 ? launch_k<TM, TN, WR, WC, false, 2>(a, s) : launch_k<TM, TN, WR, WC, false, 1>(a, s);
 }
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
 {
+    if (tile < 0 || tile >= TILE_COUNT) return hipErrorInvalidValue;
+    const int stages = kTiles[tile].stages;
     switch (tile) {
-        case TILE_128x128: return launch_t<2, 2, 2, 2>(a, s);
-        case TILE_256x64: return launch_t<2, 2, 4, 1>(a, s);
-        case TILE_256x32: return launch_t<2, 1, 4, 1>(a, s);
-        case TILE_128x64: return launch_t<1, 2, 4, 1>(a, s);
-        case TILE_64x128: return launch_t<1, 2, 2, 2>(a, s);
-        case TILE_64x64: return launch_t<1, 1, 2, 2>(a, s);
+        case 0: case 6: return launch_t<2, 2, 2, 2>(a, stages, s);    // 128x128, 4 waves
+        case 1: case 7: return launch_t<2, 2, 4, 1>(a, stages, s);    // 256x64
+        case 2: case 8: return launch_t<2, 1, 4, 1>(a, stages, s);    // 256x32
+        case 3: case 9: return launch_t<1, 2, 4, 1>(a, stages, s);    // 128x64
+        case 4: case 10: return launch_t<1, 2, 2, 2>(a, stages, s);   // 64x128
+        case 5: case 11: return launch_t<1, 1, 2, 2>(a, stages, s);   // 64x64
+        case 12: case 13: return launch_t<2, 1, 2, 4>(a, stages, s);  // 128x128, 8 waves
+        case 14: case 15: return launch_t<1, 1, 4, 4>(a, stages, s);  // 128x128, 16 waves
+        case 16: return launch_t<2, 1, 4, 4>(a, stages, s);           // 256x128, 16 waves
+        case 17: case 19: return launch_t<1, 1, 4, 2>(a, stages, s);  // 128x64, 8 waves
+        case 18: return launch_t<2, 1, 4, 2>(a, stages, s);           // 256x64, 8 waves
+        case 20: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 1>(a, s);  // probes (64x128)
+        case 21: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 2>(a, s);
+        case 22: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 3>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -87,19 +87,20 @@ void free_plan(y3_net *n)
 
 int choose_tile(const ConvSlot &c, long long M)
 {
-    using namespace y3;
+    // measured on MI355X (tools/tune_tiles.py): many co-resident waves beat big wave tiles for the 64-cycle
+    // fp32 MFMA; prefer the largest block tile that still yields >= 2 workgroups per CU
     std::vector<int> cand;
     if (c.cout_pad % 128 == 0)
-        cand = {TILE_128x128, TILE_64x128, TILE_64x64};
+        cand = {10, 11};
     else if (c.cout_pad % 64 == 0)
-        cand = {TILE_256x64, TILE_128x64, TILE_64x64};
+        cand = {11};
     else
-        cand = {TILE_256x32};
+        cand = {8};
     int best = cand.back();
     for (int t : cand) {
-        TileShape s = conv_tile_shape(t);
+        y3::TileInfo s = y3::conv_tile_info(t);
         long long blocks = ((M + s.bm - 1) / s.bm) * (c.cout_pad / s.bn);
-        if (blocks >= 512) {  // two workgroups per CU
+        if (blocks >= 1024) {
             best = t;
             break;
         }
@@ -242,7 +243,7 @@ y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
         return fail(Y3_ERR_INVALID, "y3_net_set_tile: bad argument");
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
-        y3::TileShape s = y3::conv_tile_shape(tile);
+        y3::TileInfo s = y3::conv_tile_info(tile);
         if (c.first_layer || c.cout_pad % s.bn) return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile does not divide Cout");
     }
     c.tile = tile;
@@ -391,6 +392,7 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
             a.src0_bytes = (unsigned)bytes(d.src0);
             a.src1_bytes = d.src1 >= 0 ? (unsigned)bytes(d.src1) : 0;
             a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * sizeof(float));
+            a.dst_bytes = (unsigned)bytes(d.dst);
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
             hipError_t e;

@@ -25,13 +25,13 @@ struct ConvArgs {
     int leaky;
     int M;                 // B*Ho*Wo
     int K;                 // ksize*ksize*Cin
-    unsigned src0_bytes, src1_bytes, w_bytes;
+    unsigned src0_bytes, src1_bytes, w_bytes, dst_bytes;
 };
 
-// tile configurations of the fp32 MFMA kernel (index into the dispatch table)
-enum ConvTile { TILE_128x128 = 0, TILE_256x64, TILE_256x32, TILE_128x64, TILE_64x128, TILE_64x64, TILE_COUNT };
-struct TileShape { int bm, bn; };
-TileShape conv_tile_shape(int tile);
+// tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
+static constexpr int TILE_COUNT = 23;  // 20..22 are timing-only probes
+struct TileInfo { int bm, bn, waves, stages; };
+TileInfo conv_tile_info(int tile);
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
 // first layer: 3x3 stride-1 conv with Cin=3 (direct, VALU)
