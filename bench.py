@@ -26,6 +26,8 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (guides/MI355X_MI
 def cpu_baseline(program, weights, anchors, image_size, budget_s=20.0):
     """Oracle (CPU restatement of the reference path, kind='port') on a bounded sample of the same workload."""
     import numpy as np
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))   # before libgomp starts
     from oracle import oracle as O
     x1 = np.random.default_rng(1234).random((1, image_size, image_size, 3), dtype=np.float32)
     t0 = time.time()
@@ -36,9 +38,9 @@ def cpu_baseline(program, weights, anchors, image_size, budget_s=20.0):
     t0 = time.time()
     O.detect(program, weights, xn, anchors)
     dt = time.time() - t0
-    return {"value": round(n / dt, 4), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{n} image(s) {image_size}x{image_size} end to end through oracle/ (C restatement, OpenMP, "
-                      f"{os.cpu_count()} threads); TensorFlow is not installed so the reference itself cannot be timed"}
+                      f"{cores} threads); TensorFlow is not installed so the reference itself cannot be timed"}
 
 
 def main():
@@ -80,9 +82,11 @@ def main():
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     images = torch.rand((B, S, S, 3), generator=gen, device="cuda", dtype=torch.float32)
     grids = [torch.empty((B, g, g, 3, 5 + nc), device="cuda") for g in net.grid_sizes()]
+    from yolo_v3_tf2_amd.parallel import allgather_detections
+    gathered = None
     if world > 1:
-        gathered = torch.empty((world * B, M, 7), dtype=torch.int32, device="cuda")
-        gathered_nv = torch.empty((world * B,), dtype=torch.int32, device="cuda")
+        gathered = (torch.empty((world * B, M, 7), dtype=torch.int32, device="cuda"),
+                    torch.empty((world * B,), dtype=torch.int32, device="cuda"))
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -95,11 +99,7 @@ def main():
         bboxes, cls, scores = runtime.yolo_decode_scores(grids, anchors, nc)
         sel, nv = runtime.nms_padded(bboxes, scores, M, 0.5, 0.1)
         packed = runtime.pack_detections(bboxes, cls, scores, sel, nv)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, packed)
-            dist.all_gather_into_tensor(gathered_nv, nv)
-            return gathered, gathered_nv
-        return packed, nv
+        return allgather_detections(packed, nv, out=gathered)   # RCCL all-gather when world > 1
 
     def fence():
         if world > 1:

@@ -10,7 +10,7 @@
  * in /root/reference; the reference ships no golden outputs, no weights and no hot-path
  * tests.  Each function below restates the published semantics of the
  * TF/Keras op the reference calls and cites the call site it follows.  An independent
- * PyTorch-CPU implementation (tests/test_oracle_crosscheck.py) and a literal NumPy
+ * PyTorch-CPU implementation (tests/test_oracle.py) and a literal NumPy
  * restatement of TF's tiled NMS (oracle/nms_tiled_ref.py) cross-check it.
  *
  * Arithmetic is plain fp32 in a fixed, documented order; build with -ffp-contract=off.
@@ -194,7 +194,8 @@ Y3O_API void y3o_scores(const float *conf, const float *probs, size_t n, int nc,
 /* ---------------------------------------------------------------------------
  * tf.image.non_max_suppression_padded(boxes[B,N,4], scores[B,N], M, T, S,
  * pad_to_max_output_size=True) -- sequential statement of what the tiled "v2"
- * algorithm of TF 2.8 computes.
+ * algorithm of TF 2.8 computes (literal tile-by-tile form in
+ * oracle/nms_tiled_ref.py).  tile_size = 512.
  * reference call site: core/yolo_nms.py:26-33
  * ------------------------------------------------------------------------- */
 typedef struct {
@@ -258,15 +259,30 @@ Y3O_API void y3o_nms_padded(const float *boxes_in, const float *scores_in, int B
         int n_alive = 0, n_sel = 0;
         int32_t *out = idx_out + (size_t)b * M;
         for (int m = 0; m < M; ++m) out[m] = 0;
+        if (!(T > 0.0f)) {
+            /* T <= 0 quirk of the tiled algorithm: inside a tile `max(iou) < T` never holds, so no box "can
+             * suppress others" and self-suppression removes nothing; across tiles `all(iou < T)` never holds,
+             * so every tile after the first (512 sorted positions) is wiped.  Net effect: the first tile
+             * survives untouched. */
+            const int lim = N < 512 ? N : 512;
+            for (int j = 0; j < lim && n_sel < M; ++j) {
+                const float *bj = bx + (size_t)keys[j].i * 4;
+                if (bj[0] > 0.0f || bj[1] > 0.0f || bj[2] > 0.0f || bj[3] > 0.0f) out[n_sel++] = keys[j].i;
+            }
+            num_valid[b] = n_sel;
+            free(alive);
+            free(keys);
+            continue;
+        }
         for (int j = 0; j < N && n_sel < M; ++j) {
             const float *bj = bx + (size_t)keys[j].i * 4;
             const int zero = (bj[0] == 0.0f && bj[1] == 0.0f && bj[2] == 0.0f && bj[3] == 0.0f);
             int suppressed = 0;
-            if (!(zero && T > 0.0f))
+            if (!zero)
                 for (int a = 0; a < n_alive && !suppressed; ++a)
                     if (iou_(bx + (size_t)keys[alive[a]].i * 4, bj) >= T) suppressed = 1;
             if (suppressed) continue;
-            if (!(zero && T > 0.0f)) alive[n_alive++] = j;
+            if (!zero) alive[n_alive++] = j;
             /* step 6: a position is selected iff any coordinate of its box is > 0 */
             if (bj[0] > 0.0f || bj[1] > 0.0f || bj[2] > 0.0f || bj[3] > 0.0f) out[n_sel++] = keys[j].i;
         }

@@ -1,0 +1,66 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/y3.h declares (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "y3.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(y3_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from yolo_v3_tf2_amd import _lib
+    declared = _header_functions()
+    assert declared, "no functions parsed from include/y3.h"
+    assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_library_exports_every_declared_symbol():
+    from yolo_v3_tf2_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build liby3hip.so first (python __graft_entry__.py)"
+    lib = _lib.load()
+    for name in _header_functions():
+        assert hasattr(lib, name), name
+    assert lib.y3_version() >= 100
+    assert lib.y3_device_count() >= 0
+
+
+def test_error_convention_without_compute():
+    """Invalid arguments come back as negative status + message, never an exception or abort."""
+    from yolo_v3_tf2_amd import _lib
+    lib = _lib.load()
+    st = lib.y3_net_create(None, 0, None, 0, None, 0, None, 0, 0, None, 80, None)
+    assert st == -1 and b"y3_net_create" in lib.y3_last_error()
+    assert lib.y3_nms_workspace_bytes(0, 0) == 0
+    assert lib.y3_nms_workspace_bytes(2, 10647) == 2 * 16384 * 8
+    st = lib.y3_nms_padded(None, None, 1, 10, 100, 0.5, 0.1, None, None, None, 0, None)
+    assert st == -1
+    with pytest.raises(_lib.Y3Error):
+        _lib.check(st, "y3_nms_padded")
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path refuses to run instead of silently computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from yolo_v3_tf2_amd import _lib, runtime
+    with pytest.raises(_lib.Y3Error):
+        _lib.require_gpu()
+    with pytest.raises(_lib.Y3Error):
+        runtime.nms_padded(torch.zeros(1, 4, 4), torch.zeros(1, 4), 10, 0.5, 0.1)
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "yolo-v3-tf2_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(d, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liby3oracle" not in txt, f

@@ -1,0 +1,96 @@
+"""Host-side mirror of the reference's Python surface (no GPU)."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_get_anchors_layout():
+    from yolo_v3_tf2_amd.core.utils import get_anchors
+    a = get_anchors(os.path.join(ROOT, "datasets/coco2012/anchors.txt"))
+    assert a.shape == (3, 3, 2) and a.dtype == np.float64
+    # row 0 = largest anchors (116x90, 156x198, 373x326)/416 -> coarsest grid (reference: core/utils.py:31-37)
+    assert np.allclose(a[0] * 416, [[116, 90], [156, 198], [373, 326]], atol=1e-4)
+    assert np.allclose(a[2] * 416, [[10, 13], [16, 30], [33, 23]], atol=1e-4)
+
+
+def test_signatures_match_reference_surface():
+    from yolo_v3_tf2_amd.core.parse_model import ParseModel
+    from yolo_v3_tf2_amd.core.yolo_decode_layer import yolo_decode
+    from yolo_v3_tf2_amd.core.yolo_nms import yolo_nms
+    from yolo_v3_tf2_amd.core.yolo_nms_layer import YoloNmsLayer
+    from yolo_v3_tf2_amd.inference import Inference
+    assert list(inspect.signature(ParseModel.build_model).parameters)[:6] == [
+        "self", "model_inputs", "sub_models_configs", "output_stage", "decay_factor", "nclasses"]
+    assert list(inspect.signature(yolo_decode).parameters) == ["model_output_grids", "anchors_table", "nclasses"]
+    assert list(inspect.signature(yolo_nms).parameters) == ["outputs", "yolo_max_boxes", "nms_iou_threshold",
+                                                            "nms_score_threshold"]
+    layer = YoloNmsLayer(100, 0.5, 0.1, name="nms")
+    assert (layer.yolo_max_boxes, layer.nms_iou_threshold, layer.nms_score_threshold) == (100, 0.5, 0.1)
+    keys = ["model_config_file", "classes_name_file", "anchors_file", "input_weights_path", "image_size",
+            "input_data_source", "images_dir", "tfrecords_dir", "batch_size", "image_file_path", "output_dir",
+            "yolo_max_boxes", "nms_iou_threshold", "nms_score_threshold", "bbox_color", "font_size",
+            "display_result_images", "save_model_path"]
+    assert list(inspect.signature(Inference.__call__).parameters)[1:19] == keys
+
+
+def test_detect_config_has_the_reference_keys():
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config/detect_config_coco.yaml")))
+    from yolo_v3_tf2_amd.inference import Inference
+    params = set(inspect.signature(Inference.__call__).parameters) - {"self", "weights"}
+    assert set(cfg) == params
+
+
+def test_model_builds_and_summarises_without_gpu():
+    from yolo_v3_tf2_amd.core.parse_model import ParseModel
+    m = ParseModel().create_model(80, os.path.join(ROOT, "config/models/yolov3/model.yaml"))
+    lines = []
+    m.summary(print_fn=lines.append)
+    assert any("62,001,757" in l for l in lines) and len(lines) == 78
+    with pytest.raises(RuntimeError, match="no weights"):
+        m(np.zeros((1, 416, 416, 3), np.float32))
+    with pytest.raises(FileNotFoundError):
+        m.load_weights("does/not/exist.safetensors")
+
+
+def test_resize_bilinear_half_pixel_centres():
+    """tf.image.resize default (bilinear, antialias=False): src = (dst+0.5)*in/out-0.5, edge clamped."""
+    from yolo_v3_tf2_amd.core.utils import resize_bilinear
+    img = np.arange(16, dtype=np.float32).reshape(4, 4, 1)
+    assert np.array_equal(resize_bilinear(img, 4, 4), img)                    # identity
+    up = resize_bilinear(img, 8, 8)
+    # closed form for a linear ramp: interior values follow the ramp, borders clamp
+    xs = np.clip((np.arange(8) + 0.5) * 0.5 - 0.5, 0, 3)
+    ref = (xs[:, None] * 4 + xs[None, :]).astype(np.float32)[..., None]
+    assert np.allclose(up, ref, atol=1e-6)
+    down = resize_bilinear(img, 2, 2)                                          # taps at 0.5 and 2.5
+    assert np.allclose(down[..., 0], [[2.5, 4.5], [10.5, 12.5]])
+
+
+def test_gather_valid_and_detect_line_format():
+    from yolo_v3_tf2_amd.inference import Inference
+    bb = np.arange(40, dtype=np.float32).reshape(10, 4) / 40
+    cc = np.arange(10, dtype=np.int64)
+    ss = np.linspace(0.9, 0.1, 10).astype(np.float32)
+    sel = np.array([7, 2, 5, 0, 0], np.int32)
+    b, c, s = Inference.gather_valid_detections_results(bb, cc, ss, sel, 3)
+    assert np.array_equal(b, bb[[7, 2, 5]]) and c.tolist() == [7, 2, 5] and np.array_equal(s, ss[[7, 2, 5]])
+    img = np.zeros((20, 40, 3), np.float32)
+    pil, det = Inference.annotate(img, b, ["a", "b", "c"], s, 15)
+    assert pil.size == (40, 20) and len(det) == 3
+    label, xmin, ymin, xmax, ymax = det[0]
+    assert label == "a: {}%".format(int(100 * s[0])) and np.isclose(xmin, b[0, 0] * 40) and np.isclose(ymax, b[0, 3] * 20)
+    assert str(det).startswith("[('a: ")          # the detect.txt payload is str(list of tuples)
+
+
+def test_shard_range_covers_batch():
+    from yolo_v3_tf2_amd.parallel import shard_range
+    for n in (0, 1, 7, 64, 513):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(e - s for s, e in r) - min(e - s for s, e in r) <= 1

@@ -114,7 +114,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
         }
     }
     __syncthreads();
-    const int nc = s_cnt;
+    // T <= 0 (tile quirk, see oracle/y3_oracle.c): nothing is suppressed inside the first 512 sorted positions and
+    // everything behind them is wiped.  (The host rejects T <= 0 together with S < 0, where zeroed boxes could
+    // sort in front of kept ones.)
+    const bool degenerate = !(p.T > 0.0f);
+    int nc = s_cnt;
     // ---- 2. sort ------------------------------------------------------------------------------------
     int P = 1;
     while (P < nc) P <<= 1;
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
     }
     __syncthreads();
     bitonic_sort(keys, P, tid);
+    if (degenerate) nc = min(nc, 512);
 
     // ---- 3. greedy suppression, 256 sorted candidates at a time ---------------------------------------
     for (int pos = 0; pos < nc; pos += NMS_THREADS) {
@@ -142,8 +147,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
             if (swap_y) { const float t = mine[0]; mine[0] = mine[2]; mine[2] = t; }
             if (swap_x) { const float t = mine[1]; mine[1] = mine[3]; mine[3] = t; }
             ok = true;
-            for (int a = 0; a < nalive; ++a)
-                if (iou_tf(*reinterpret_cast<const f32x4 *>(s_kbox + a * 4), mine) >= p.T) ok = false;
+            if (!degenerate)
+                for (int a = 0; a < nalive; ++a)
+                    if (iou_tf(*reinterpret_cast<const f32x4 *>(s_kbox + a * 4), mine) >= p.T) ok = false;
         }
         *reinterpret_cast<f32x4 *>(s_cbox + tid * 4) = mine;
         const u64 bal = __ballot(ok);
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
         __syncthreads();
         // suppression row of this candidate over the later candidates of the chunk
         u64 row[4] = {0, 0, 0, 0};
-        if (ok) {
+        if (ok && !degenerate) {
             for (int j = tid + 1; j < cnt; ++j) {
                 if (iou_tf(mine, *reinterpret_cast<const f32x4 *>(s_cbox + j * 4)) >= p.T) row[j >> 6] |= 1ull << (j & 63);
             }
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
                 while (rem) {
                     const int i = __builtin_ctzll(rem);
                     const int t = w * 64 + i;
-                    if (nal >= KEPT_CAP) {
+                    if (nal >= KEPT_CAP && !degenerate) {
                         if (tid == 0) s_overflow = 1;
                         full = true;
                         break;
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
         }
         __syncthreads();
         const int nk = s_nkept_chunk;
-        if (tid < nk) {
+        if (tid < nk && !degenerate) {
             const int t = s_keptpos[tid];
             *reinterpret_cast<f32x4 *>(s_kbox + (nalive + tid) * 4) = *reinterpret_cast<const f32x4 *>(s_cbox + t * 4);
         }
@@ -210,44 +216,6 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
         if (s_nsel >= p.M || s_overflow) break;
     }
     if (tid == 0) p.num_valid[b] = s_overflow ? -1 : s_nsel;
-}
-
-// iou_threshold <= 0: the box at sorted position 0 suppresses every other box (IoU >= T always holds);
-// that box is selected iff it passed the score filter and has a positive coordinate.
-__global__ __launch_bounds__(NMS_THREADS) void nms_degenerate_kernel(const NmsArgs p)
-{
-    __shared__ u64 s_best[NMS_THREADS];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const float *scores = p.scores + (size_t)b * p.N;
-    int32_t *sel = p.sel + (size_t)b * p.M;
-    u64 best = ~0ull;
-    for (int i = tid; i < p.N; i += NMS_THREADS) {
-        const float s = scores[i];
-        const float ms = (s > p.S) ? s : s * 0.0f;
-        const u64 k = ((u64)score_key(ms) << 32) | (unsigned)i;
-        best = k < best ? k : best;
-    }
-    s_best[tid] = best;
-    for (int i = tid; i < p.M; i += NMS_THREADS) sel[i] = 0;
-    __syncthreads();
-    for (int st = NMS_THREADS / 2; st > 0; st >>= 1) {
-        if (tid < st) s_best[tid] = s_best[tid + st] < s_best[tid] ? s_best[tid + st] : s_best[tid];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        int nv = 0;
-        if (p.N > 0 && p.M > 0) {
-            const int i = (int)(unsigned)(s_best[0] & 0xFFFFFFFFull);
-            if (scores[i] > p.S) {
-                const float *bx = p.boxes + ((size_t)b * p.N + i) * 4;
-                if (bx[0] > 0.0f || bx[1] > 0.0f || bx[2] > 0.0f || bx[3] > 0.0f) {
-                    sel[0] = i;
-                    nv = 1;
-                }
-            }
-        }
-        p.num_valid[b] = nv;
-    }
 }
 
 static int next_pow2(int n)
@@ -264,10 +232,7 @@ hipError_t launch_nms(const float *boxes, const float *scores, int B, int N, int
 {
     NmsArgs a{boxes, scores, N, M, T, S, sel, num_valid, static_cast<u64 *>(ws), next_pow2(N > 1 ? N : 1)};
     dim3 grid(B), block(NMS_THREADS);
-    if (T > 0.0f)
-        hipLaunchKernelGGL(nms_kernel, grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL(nms_degenerate_kernel, grid, block, 0, s, a);
+    hipLaunchKernelGGL(nms_kernel, grid, block, 0, s, a);
     return hipGetLastError();
 }
 

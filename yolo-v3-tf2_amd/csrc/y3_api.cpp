@@ -538,6 +538,8 @@ y3_status y3_nms_padded(const float *bboxes_dev, const float *scores_dev, int ba
     if (max_output_size <= 0 || max_output_size > 1024)
         return fail(Y3_ERR_INVALID, "y3_nms_padded: max_output_size must be in [1,1024]");
     if ((uintptr_t)bboxes_dev & 15) return fail(Y3_ERR_INVALID, "y3_nms_padded: bboxes not 16-byte aligned");
+    if (!(iou_threshold > 0.0f) && score_threshold < 0.0f)
+        return fail(Y3_ERR_INVALID, "y3_nms_padded: iou_threshold <= 0 together with score_threshold < 0 is not supported");
     if (!workspace_dev || workspace_bytes < y3::nms_workspace_bytes(batch, n))
         return fail(Y3_ERR_INVALID, "y3_nms_padded: workspace too small (need %zu bytes)", y3::nms_workspace_bytes(batch, n));
     hipError_t e = y3::launch_nms(bboxes_dev, scores_dev, batch, n, max_output_size, iou_threshold, score_threshold,
