@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per forward (y3_net_set_lanes)")
+    ap.add_argument("--graph", action="store_true", help="capture the per-batch pipeline in a HIP graph and replay it")
     ap.add_argument("--per-layer", action="store_true", help="also print the per-conv timing table to stderr")
     args = ap.parse_args()
 
@@ -79,6 +81,7 @@ def main():
     net = runtime.Net(program)
     net.load_weights(weights)
     net.plan(B, S)
+    net.set_lanes(args.lanes)
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     images = torch.rand((B, S, S, 3), generator=gen, device="cuda", dtype=torch.float32)
     grids = [torch.empty((B, g, g, 3, 5 + nc), device="cuda") for g in net.grid_sizes()]
@@ -107,11 +110,26 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        out = step()
+    graph = None
+    if args.graph and world == 1:
+        # one replay = one step; the conv-stack events are recorded inside the captured stream once
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        graph.replay()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(i)
+        if graph is not None:
+            graph.replay()
+        else:
+            out = step(i)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -120,6 +138,12 @@ def main():
         dt = float(t.item())
     nv_mean = float(out[1].float().mean().item())
 
+    if graph is not None:   # events cannot be read out of a replayed graph: time the conv stack eagerly afterwards
+        for i in range(args.steps):
+            ev[i][0].record()
+            net.forward(images, out=grids)
+            ev[i][1].record()
+        torch.cuda.synchronize()
     conv_ms = sorted(a.elapsed_time(b) for a, b in ev)
     conv_ms_mean = sum(conv_ms) / len(conv_ms)
     flops_step = net.flops_per_image() * B

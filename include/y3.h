@@ -107,6 +107,10 @@ y3_status y3_net_set_conv_weights(y3_net *net, int conv_slot, const float *w, co
  * y3_net_keep_activations(1) before y3_net_plan: no buffer reuse, so y3_net_read_tensor can read any
  * intermediate after a forward. */
 y3_status y3_net_set_tile(y3_net *net, int conv_slot, int tile);
+/* Run a forward as `lanes` (1..4) equal sub-batches on forked internal streams joined back into the caller's
+ * stream: the tail of one sub-batch's conv kernel overlaps the next kernel of another.  Results are unchanged
+ * (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
+y3_status y3_net_set_lanes(y3_net *net, int lanes);
 y3_status y3_net_keep_activations(y3_net *net, int keep);
 
 /* Allocate the activation arena for batches up to `max_batch` of image_size x image_size inputs

@@ -131,6 +131,92 @@ def test_forward_is_deterministic(rt, program, weights):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_forward_lanes_bit_identical(rt, program, weights, lanes):
+    """Sub-batches on forked streams (y3_net_set_lanes) give exactly the single-stream result."""
+    x = _cuda(np.random.default_rng(6).random((4, 96, 96, 3), dtype=np.float32))
+    net = rt.Net(program)
+    net.load_weights(weights)
+    a = [g.clone() for g in net.forward(x)]
+    net.set_lanes(lanes)
+    b = net.forward(x)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_full_size_batch_properties(rt, program, weights, anchors):
+    """BASELINE size (batch 64, 416x416) through size-independent properties: (1) determinism, (2) batch
+    independence -- image i of the 64-batch equals the same image run alone, bit for bit (the per-pixel K order does
+    not depend on the tile an output pixel falls in), (3) the detect pipeline on the batch equals per-image runs."""
+    B, S = 64, 416
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand((B, S, S, 3), generator=gen, device="cuda")
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(B, S)
+    g1 = [t.clone() for t in net.forward(x)]
+    g2 = net.forward(x)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+    for i in (0, 17, 63):
+        gi = net.forward(x[i:i + 1].contiguous())
+        assert all(torch.equal(a[i:i + 1], b) for a, b in zip(g1, gi))
+    bb, cls, sc = rt.yolo_decode_scores(g1, anchors, 80)
+    sel, nv = rt.nms_padded(bb, sc, 100, 0.5, 0.1)
+    assert bb.shape == (B, 10647, 4) and sel.shape == (B, 100) and int(nv.min()) >= 0 and int(nv.max()) <= 100
+    for i in (3, 40):
+        s1, n1 = rt.nms_padded(bb[i:i + 1].contiguous(), sc[i:i + 1].contiguous(), 100, 0.5, 0.1)
+        assert torch.equal(s1[0], sel[i]) and int(n1[0]) == int(nv[i])
+    # selected boxes are sorted by score and all above the threshold
+    scn, seln, nvn = sc.cpu().numpy(), sel.cpu().numpy(), nv.cpu().numpy()
+    for i in range(B):
+        s_ = scn[i, seln[i, :nvn[i]]]
+        assert (s_ > 0.1).all() and (np.diff(s_) <= 0).all()
+
+
+def test_608_grids_match_oracle(rt, program, weights):
+    """BASELINE config 3 geometry: 608x608 -> grids 19/38/76 (the reference's YAML hard-codes 13/26/52, F5)."""
+    from oracle import oracle as O
+    x = np.random.default_rng(608).random((1, 608, 608, 3), dtype=np.float32)
+    ref = O.forward(program, weights, x)
+    net = rt.Net(program)
+    net.load_weights(weights)
+    got = net.forward(_cuda(x))
+    assert [g.shape[1] for g in got] == [19, 38, 76]
+    for r, g in zip(ref, got):
+        assert np.abs(g.cpu().numpy() - r).max() <= 1e-4
+
+
+def test_hipgraph_capture_replays_identically(rt, program, weights, anchors):
+    """The whole per-batch pipeline (conv program incl. forked lanes, decode, NMS, pack) captured in a HIP graph."""
+    x = _cuda(np.random.default_rng(9).random((4, 96, 96, 3), dtype=np.float32))
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(4, 96)
+    net.set_lanes(2)
+
+    def step():
+        grids = net.forward(x)
+        bb, cls, sc = rt.yolo_decode_scores(grids, anchors, 80)
+        sel, nv = rt.nms_padded(bb, sc, 100, 0.5, 0.1)
+        return rt.pack_detections(bb, cls, sc, sel, nv), nv
+
+    ref_p, ref_n = step()
+    ref_p, ref_n = ref_p.clone(), ref_n.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out_p, out_n = step()
+    out_p.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_p, ref_p) and torch.equal(out_n, ref_n)
+
+
 # ---------------------------------------------------------------------------------------------- decode
 @pytest.mark.parametrize("gs,B,nc", [((13, 26, 52), 2, 80), ((3, 6, 12), 5, 80), ((19, 38, 76), 1, 80), ((2, 4, 8), 3, 7)])
 def test_decode_matches_oracle(rt, anchors, gs, B, nc):

@@ -21,7 +21,8 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
          (128, 128, 4, 1), (256, 64, 4, 1), (256, 32, 4, 1), (128, 64, 4, 1), (64, 128, 4, 1), (64, 64, 4, 1),
          (128, 128, 8, 1), (128, 128, 8, 2), (128, 128, 16, 1), (128, 128, 16, 2),
          (256, 128, 16, 1), (128, 64, 8, 1), (256, 64, 8, 1), (128, 64, 8, 2),
-         (64, 128, 4, 1), (64, 128, 4, 1), (64, 128, 4, 1)]  # 20..22: timing-only probes (wrong results)
+         (64, 128, 4, 1), (64, 128, 4, 1), (64, 128, 4, 1),  # 20..22: timing-only probes (wrong results)
+         (128, 128, 4, 1), (128, 128, 4, 1)]                # 23/24: 128x128 within 3 / 4 waves per SIMD of registers
 N_REAL_TILES = 20
 TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" for bm, bn, w, st in TILES]
 
@@ -58,6 +59,7 @@ SYMBOLS = {
     "y3_net_set_conv_weights": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f]),
     "y3_net_set_tile": (_i, [_vp, _i, _i]),
     "y3_net_keep_activations": (_i, [_vp, _i]),
+    "y3_net_set_lanes": (_i, [_vp, _i]),
     "y3_net_plan": (_i, [_vp, _i, _i, _i]),
     "y3_net_forward": (_i, [_vp, _vp, _i, C.POINTER(_vp), _vp]),
     "y3_net_read_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_sz), _vp]),

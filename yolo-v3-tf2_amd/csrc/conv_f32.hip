@@ -16,6 +16,8 @@
 // contracted exactly once (the order of k inside a tile is irrelevant to the sum's value up to
 // fp32 rounding).
 // Epilogue from the accumulators: y = acc*scale[n] + shift[n]; leaky; + residual; store.
+#include <type_traits>
+
 #include "y3_kernels.h"
 
 namespace y3 {
@@ -36,8 +38,8 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 
 // PROBE != 0 builds timing-only ablations of the main loop (wrong results; tools/tune_tiles.py --probe):
 //   1: LDS fragment reads + MFMA only   2: 1 + the two barriers   3: 2 + global fetches (never staged)
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0>
-__global__ __launch_bounds__(64 * WR * WC) void conv_f32_mfma(const ConvArgs p)
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1>
+__global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvArgs p)
 {
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
@@ -82,13 +84,24 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32_mfma(const ConvArgs p)
     int ahw[AP];                       // hi0 << 16 | (wi0 & 0xffff); row >= M marked by hi0 = -32768
     const int HoWo = p.Ho * p.Wo;
     const int C1 = p.Cin - p.C0;
+    // (b, ho, wo) of row m: the tile's first row is decomposed with wave-uniform (scalar) divisions; the lane's
+    // displacement (< BM + Wo) is folded in with an exact small float division -- vector integer division costs
+    // ~40 VALU instructions each, and VALU time is lost MFMA time for every wave on the SIMD.
+    const int b0 = m0 / HoWo;
+    const int r0 = m0 - b0 * HoWo;
+    const int ho0 = r0 / p.Wo;
+    const int wo0 = r0 - ho0 * p.Wo;
+    const float rcpW = 1.0f / (float)p.Wo, rcpH = 1.0f / (float)p.Ho;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + i * RP + lrow;
-        int b = m / HoWo;
-        int r = m - b * HoWo;
-        int ho = r / p.Wo;
-        int wo = r - ho * p.Wo;
+        const int x = wo0 + i * RP + lrow;                       // < BM + Wo <= 1024: (x+0.5)*rcp is exact
+        const int qx = (int)(((float)x + 0.5f) * rcpW);
+        const int wo = x - qx * p.Wo;
+        const int y = ho0 + qx;
+        const int qy = (int)(((float)y + 0.5f) * rcpH);
+        const int ho = y - qy * p.Ho;
+        const int b = b0 + qy;
         if (CONCAT) {
             // 1x1 conv: src0 optionally read through nearest x2 up-sampling
             const int H0 = p.up0 ? (p.H >> 1) : p.H, W0 = p.up0 ? (p.W >> 1) : p.W;
@@ -235,35 +248,58 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32_mfma(const ConvArgs p)
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(p.residual ? p.residual : p.dst), 0, p.dst_bytes, 0x00020000);
-    const bool has_res = p.residual != nullptr;
+    // interior tiles (the common case): one per-lane voffset per sub-tile, the row displacement of accumulator
+    // element e rides in the scalar soffset -> no per-element address or bounds arithmetic on the VALU
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
+    const int row_bytes = p.Cout * 4;
+    auto emit = [&](auto leaky_tag, auto res_tag) {
+        constexpr bool LEAKY = decltype(leaky_tag)::value, RES = decltype(res_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wc * TN + j) * 32 + fr;
-        const float sc = p.scale[n], sh = p.shift[n];
-        const bool n_ok = n < p.Cout;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wc * TN + j) * 32 + fr;
+            const float sc = p.scale[n], sh = p.shift[n];
+            const bool n_ok = n < p.Cout;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mbase = m0 + (wr * TM + i) * 32 + 4 * fh;
-            unsigned off[16];
+            for (int i = 0; i < TM; ++i) {
+                const int mbase = m0 + (wr * TM + i) * 32 + 4 * fh;
+                const unsigned vbase = (unsigned)(mbase * p.Cout + n) * 4u;
+                unsigned off[16];
+                if (!interior) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mbase + (e & 3) + 8 * (e >> 2);
-                off[e] = (n_ok && m < p.M) ? (unsigned)(m * p.Cout + n) * 4u : p.dst_bytes;
-            }
-            float r[16];
-            if (has_res) {
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mbase + (e & 3) + 8 * (e >> 2);
+                        off[e] = (n_ok && m < p.M) ? (unsigned)(m * p.Cout + n) * 4u : p.dst_bytes;
+                    }
+                }
+                float r[16];
+                if (RES) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    r[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)off[e], 0, 0));
-            }
+                    for (int e = 0; e < 16; ++e) {
+                        const int so = ((e & 3) + 8 * (e >> 2)) * row_bytes;
+                        r[e] = __builtin_bit_cast(float, interior ? __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)vbase, so, 0)
+                                                                  : __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)off[e], 0, 0));
+                    }
+                }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] * sc + sh;
-                if (p.leaky) v = (v >= 0.0f) ? v : 0.1f * v;
-                if (has_res) v = r[e] + v;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, (int)off[e], 0, 0);
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][j][e] * sc + sh;
+                    if (LEAKY) v = fmaxf(v, 0.1f * v);   // == (v >= 0 ? v : 0.1 v) for every finite v
+                    if (RES) v = r[e] + v;
+                    const int so = ((e & 3) + 8 * (e >> 2)) * row_bytes;
+                    if (interior)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, (int)vbase, so, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, (int)off[e], 0, 0);
+                }
             }
         }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (p.residual) {
+        if (p.leaky) emit(T_{}, T_{}); else emit(F_{}, T_{});
+    } else {
+        if (p.leaky) emit(T_{}, F_{}); else emit(F_{}, F_{});
     }
 }
 
@@ -274,17 +310,18 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {128, 128, 8, 1}, {128, 128, 8, 2}, {128, 128, 16, 1}, {128, 128, 16, 2},
     {256, 128, 16, 1}, {128, 64, 8, 1}, {256, 64, 8, 1}, {128, 64, 8, 2},
     {64, 128, 4, 1}, {64, 128, 4, 1}, {64, 128, 4, 1},  // timing-only probes of tile 10 (wrong results)
+    {128, 128, 4, 1}, {128, 128, 4, 1},                  // 128x128 with the register budget of 3 / 4 waves per SIMD
 };
 
 TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUNT) ? tile : 0]; }
 
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0>
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1>
 static hipError_t launch_k(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
     const size_t lds = STAGES * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
-    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE>;
+    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE, MINW>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -322,6 +359,8 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 20: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 1>(a, s);  // probes (64x128)
         case 21: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 2>(a, s);
         case 22: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 3>(a, s);
+        case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 3>(a, s);
+        case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 4>(a, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -335,11 +374,18 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_first_f32(const ConvArgs p, const float *__restrict__ w)
 {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= p.M) return;
+    // per-wave transpose buffer: 64 pixels x (COUT + 4) floats (row stride 9 x 16 B -> conflict-free b128 access)
+    constexpr int ROW = COUT + 4;
+    __shared__ __attribute__((aligned(16))) float tr[4][64 * ROW];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int mw = blockIdx.x * 256 + wave * 64;  // first pixel of this wave
+    const int m = mw + lane;
     const int HW = p.H * p.W;
-    const int b = m / HW;
-    const int r = m - b * HW;
+    const bool live = m < p.M;
+    const int mm = live ? m : 0;
+    const int b = mm / HW;
+    const int r = mm - b * HW;
     const int ho = r / p.W, wo = r - ho * p.W;
     const float *x = static_cast<const float *>(p.src0);
     float acc[COUT];
@@ -351,30 +397,44 @@ __global__ __launch_bounds__(256) void conv_first_f32(const ConvArgs p, const fl
 #pragma unroll 1
         for (int v = 0; v < 3; ++v) {
             const int wi = wo - 1 + v;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const bool ok = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             const float *xp = x + ((size_t)(b * p.H + (ok ? hi : 0)) * p.W + (ok ? wi : 0)) * 3;
             float xv[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) xv[c] = ok ? xp[c] : 0.0f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float *wr = w + ((u * 3 + v) * 3 + c) * COUT;  // HWIO, wave-uniform address
+                const float *wr = w + ((u * 3 + v) * 3 + c) * COUT;  // HWIO, wave-uniform address -> scalar loads
 #pragma unroll
                 for (int n = 0; n < COUT; ++n) acc[n] += xv[c] * wr[n];
             }
         }
     }
-    float *dst = static_cast<float *>(p.dst) + (size_t)m * COUT;
+    // epilogue into LDS (lane = pixel), then 16-B stores with 8 lanes per pixel: every wave store instruction
+    // writes 1 KiB of contiguous NHWC output (the lane-per-pixel store wrote 16 B per 128-B line and cost 2.2x
+    // the bytes at the memory side: WRITE_SIZE in profiles/r01_derived.txt)
+    float *t = tr[wave];
 #pragma unroll
     for (int n = 0; n < COUT; n += 4) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = acc[n + e] * p.scale[n + e] + p.shift[n + e];
-            if (p.leaky) v = (v >= 0.0f) ? v : 0.1f * v;
+            if (p.leaky) v = fmaxf(v, 0.1f * v);
             o[e] = v;
         }
-        *reinterpret_cast<f32x4 *>(dst + n) = o;
+        *reinterpret_cast<f32x4 *>(t + lane * ROW + n) = o;
+    }
+    // same wave wrote and reads: no barrier needed, only the LDS counter (compiler inserts the wait)
+    float *dst = static_cast<float *>(p.dst);
+    constexpr int CH = COUT / 4;           // 16-B chunks per pixel
+    constexpr int PPI = 64 / CH;           // pixels per store instruction
+    const int c4 = lane % CH, pl = lane / CH;
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+        const int px = it * PPI + pl;
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(t + px * ROW + c4 * 4);
+        if (mw + px < p.M) *reinterpret_cast<f32x4 *>(dst + (size_t)(mw + px) * COUT + c4 * 4) = o;
     }
 }
 

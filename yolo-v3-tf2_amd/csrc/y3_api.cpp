@@ -55,6 +55,8 @@ struct Op {
     int index;
 };
 
+constexpr int Y3_MAX_LANES = 4;
+
 }  // namespace
 
 struct y3_net {
@@ -69,8 +71,13 @@ struct y3_net {
     // plan
     int max_batch = 0, image_size = 0, dtype = Y3_DTYPE_F32;
     int keep_all = 0;              // 1: no buffer reuse, every intermediate stays readable after a forward
+    int lanes = 1;                 // sub-batches run concurrently on forked streams (y3_net_set_lanes)
+    hipEvent_t fork_ev = nullptr;
+    hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<void *> tdev;      // arena pointer per tensor (nullptr: not materialised / external)
     std::vector<size_t> tbytes;    // bytes at max_batch
+    std::vector<size_t> tblock;    // size of the arena block the tensor lives in
     std::vector<void *> blocks;    // distinct hipMalloc'ed blocks
 };
 
@@ -181,6 +188,7 @@ y3_status y3_net_create(const y3_tensor_desc *tensors, int n_tensors, const int3
     net->nclasses = nclasses;
     net->tdev.assign(n_tensors, nullptr);
     net->tbytes.assign(n_tensors, 0);
+    net->tblock.assign(n_tensors, 0);
     *out = net;
     return Y3_OK;
 }
@@ -189,6 +197,13 @@ void y3_net_destroy(y3_net *net)
 {
     if (!net) return;
     free_plan(net);
+    if (net->fork_ev) {
+        (void)hipEventDestroy(net->fork_ev);
+        for (int i = 0; i < Y3_MAX_LANES; ++i) {
+            (void)hipStreamDestroy(net->lane_stream[i]);
+            (void)hipEventDestroy(net->join_ev[i]);
+        }
+    }
     for (ConvSlot &c : net->convs) {
         if (c.w_dev) (void)hipFree(c.w_dev);
         if (c.scale_dev) (void)hipFree(c.scale_dev);
@@ -247,6 +262,13 @@ y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
         if (c.first_layer || c.cout_pad % s.bn) return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile does not divide Cout");
     }
     c.tile = tile;
+    return Y3_OK;
+}
+
+y3_status y3_net_set_lanes(y3_net *net, int lanes)
+{
+    if (!net || lanes < 1 || lanes > Y3_MAX_LANES) return fail(Y3_ERR_INVALID, "y3_net_set_lanes: lanes must be in [1,%d]", Y3_MAX_LANES);
+    net->lanes = lanes;
     return Y3_OK;
 }
 
@@ -310,7 +332,7 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
                 pick = k;
         if (pick < 0) {
             void *p = nullptr;
-            hipError_t e = hipMalloc(&p, net->tbytes[t]);
+            hipError_t e = hipMalloc(&p, net->tbytes[t] + 4096);
             if (e != hipSuccess) {
                 free_plan(net);
                 return fail(Y3_ERR_OOM, "y3_net_plan: hipMalloc(%zu) failed: %s", net->tbytes[t], hipGetErrorString(e));
@@ -321,6 +343,7 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
         }
         pool[pick].free_at = until;
         net->tdev[t] = pool[pick].p;
+        net->tblock[t] = pool[pick].bytes;
     }
     return Y3_OK;
 }
@@ -336,28 +359,29 @@ double y3_net_flops_per_image(const y3_net *net)
     return tot;
 }
 
-static y3_status run(y3_net *net, const float *images, int batch, float *const grids[3], hipStream_t s,
-                     float *ms_out, int n_ms)
+// Enqueue the whole op list for images [b0, b0+nb) of the batch on stream s (tensor pointers offset by b0 images).
+static y3_status run_slice(y3_net *net, const float *images, float *const grids[3], int b0, int nb, hipStream_t s,
+                           float *ms_out, int n_ms, int lane = 0, int lanes = 1)
 {
-    if (!net || !images || !grids || batch <= 0) return fail(Y3_ERR_INVALID, "y3_net_forward: bad argument");
-    if (!net->image_size) return fail(Y3_ERR_STATE, "y3_net_forward: call y3_net_plan first");
-    if (batch > net->max_batch) return fail(Y3_ERR_INVALID, "y3_net_forward: batch %d > planned %d", batch, net->max_batch);
-    for (size_t i = 0; i < net->convs.size(); ++i)
-        if (!net->convs[i].loaded) return fail(Y3_ERR_STATE, "y3_net_forward: conv %zu has no weights", i);
-    for (int i = 0; i < 3; ++i)
-        if (!grids[i] || ((uintptr_t)grids[i] & 15)) return fail(Y3_ERR_INVALID, "y3_net_forward: grid %d null or not 16-byte aligned", i);
-    if ((uintptr_t)images & 3) return fail(Y3_ERR_INVALID, "y3_net_forward: images not 4-byte aligned");
+    auto img_elems = [&](int t) -> size_t {
+        const int sp = spatial(net, t);
+        return (size_t)sp * sp * net->tensors[t].channels;
+    };
     auto ptr = [&](int t) -> void * {
         if (t < 0) return nullptr;
-        if (t == net->input_tensor) return const_cast<float *>(images);
-        for (int i = 0; i < 3; ++i)
-            if (t == net->outputs[i]) return grids[i];
-        return net->tdev[t];
+        float *base = nullptr;
+        if (t == net->input_tensor) base = const_cast<float *>(images);
+        for (int i = 0; i < 3 && !base; ++i)
+            if (t == net->outputs[i]) base = grids[i];
+        if (base) return base + (size_t)b0 * img_elems(t);
+        // arena tensors share blocks with other (dead) tensors of different per-image size: give every lane its
+        // own 1/lanes region of the block so that concurrent sub-batches never alias
+        char *blk = static_cast<char *>(net->tdev[t]);
+        if (!blk) return nullptr;
+        const size_t region = (net->tblock[t] / lanes + 255) & ~(size_t)255;  // blocks carry 4 KiB of slack
+        return blk + (size_t)lane * region;
     };
-    auto bytes = [&](int t) -> size_t {
-        const int sp = spatial(net, t);
-        return (size_t)batch * sp * sp * net->tensors[t].channels * sizeof(float);
-    };
+    auto bytes = [&](int t) -> size_t { return (size_t)nb * img_elems(t) * sizeof(float); };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ms_out) {
         HIP_TRY(hipEventCreate(&ev0));
@@ -375,7 +399,7 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
             a.shift = c.shift_dev;
             a.residual = ptr(d.residual);
             a.dst = ptr(d.dst);
-            a.B = batch;
+            a.B = nb;
             a.H = a.W = net->image_size / d.in_div;
             a.Ho = a.Wo = net->image_size / d.out_div;
             a.Cin = d.cin;
@@ -387,7 +411,7 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
             a.pad = (d.size == 3) ? 1 : 0;
             a.up0 = d.src0_upsample;
             a.leaky = d.leaky;
-            a.M = batch * a.Ho * a.Wo;
+            a.M = nb * a.Ho * a.Wo;
             a.K = c.K;
             a.src0_bytes = (unsigned)bytes(d.src0);
             a.src1_bytes = d.src1 >= 0 ? (unsigned)bytes(d.src1) : 0;
@@ -417,13 +441,13 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
             hipError_t e = hipSuccess;
             if (x.kind == Y3_AUX_ADD)
                 e = y3::launch_add((const float *)ptr(x.src0), (const float *)ptr(x.src1), (float *)ptr(x.dst),
-                                   (size_t)batch * sp * sp * C, s);
+                                   (size_t)nb * sp * sp * C, s);
             else if (x.kind == Y3_AUX_UPSAMPLE2X)
-                e = y3::launch_upsample2x((const float *)ptr(x.src0), batch, sp / 2, sp / 2, C, (float *)ptr(x.dst), s);
+                e = y3::launch_upsample2x((const float *)ptr(x.src0), nb, sp / 2, sp / 2, C, (float *)ptr(x.dst), s);
             else if (x.kind == Y3_AUX_CONCAT)
                 e = y3::launch_concat((const float *)ptr(x.src0), net->tensors[x.src0].channels,
                                       (const float *)ptr(x.src1), net->tensors[x.src1].channels,
-                                      (size_t)batch * sp * sp, (float *)ptr(x.dst), s);
+                                      (size_t)nb * sp * sp, (float *)ptr(x.dst), s);
             else
                 return fail(Y3_ERR_INVALID, "unknown aux op kind %d", x.kind);
             if (e != hipSuccess) return fail(Y3_ERR_HIP, "aux op %d launch: %s", o.index, hipGetErrorString(e));
@@ -432,6 +456,42 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
     if (ms_out) {
         (void)hipEventDestroy(ev0);
         (void)hipEventDestroy(ev1);
+    }
+    return Y3_OK;
+}
+
+static y3_status run(y3_net *net, const float *images, int batch, float *const grids[3], hipStream_t s,
+                     float *ms_out, int n_ms)
+{
+    if (!net || !images || !grids || batch <= 0) return fail(Y3_ERR_INVALID, "y3_net_forward: bad argument");
+    if (!net->image_size) return fail(Y3_ERR_STATE, "y3_net_forward: call y3_net_plan first");
+    if (batch > net->max_batch) return fail(Y3_ERR_INVALID, "y3_net_forward: batch %d > planned %d", batch, net->max_batch);
+    for (size_t i = 0; i < net->convs.size(); ++i)
+        if (!net->convs[i].loaded) return fail(Y3_ERR_STATE, "y3_net_forward: conv %zu has no weights", i);
+    for (int i = 0; i < 3; ++i)
+        if (!grids[i] || ((uintptr_t)grids[i] & 15)) return fail(Y3_ERR_INVALID, "y3_net_forward: grid %d null or not 16-byte aligned", i);
+    if ((uintptr_t)images & 3) return fail(Y3_ERR_INVALID, "y3_net_forward: images not 4-byte aligned");
+    // Images are independent, so the batch can run as `lanes` sub-batches on forked streams: while one sub-batch's
+    // conv kernel drains (its last workgroups leave CUs under-occupied), the other sub-batch's kernel fills them.
+    int lanes = (ms_out || net->lanes < 2) ? 1 : net->lanes;
+    while (lanes > 1 && (batch % lanes || batch / lanes < 1)) --lanes;
+    if (lanes == 1) return run_slice(net, images, grids, 0, batch, s, ms_out, n_ms);
+    HIP_TRY(hipSetDevice(net->device));
+    if (!net->fork_ev) {
+        HIP_TRY(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
+        for (int i = 0; i < Y3_MAX_LANES; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&net->lane_stream[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&net->join_ev[i], hipEventDisableTiming));
+        }
+    }
+    HIP_TRY(hipEventRecord(net->fork_ev, s));
+    const int nb = batch / lanes;
+    for (int l = 0; l < lanes; ++l) {
+        HIP_TRY(hipStreamWaitEvent(net->lane_stream[l], net->fork_ev, 0));
+        y3_status st = run_slice(net, images, grids, l * nb, nb, net->lane_stream[l], nullptr, 0, l, lanes);
+        if (st != Y3_OK) return st;
+        HIP_TRY(hipEventRecord(net->join_ev[l], net->lane_stream[l]));
+        HIP_TRY(hipStreamWaitEvent(s, net->join_ev[l], 0));
     }
     return Y3_OK;
 }

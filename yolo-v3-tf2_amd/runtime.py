@@ -97,6 +97,9 @@ class Net:
     def keep_activations(self, keep=True):
         check(self.lib.y3_net_keep_activations(self._h, int(keep)), "y3_net_keep_activations")
 
+    def set_lanes(self, lanes: int):
+        check(self.lib.y3_net_set_lanes(self._h, int(lanes)), "y3_net_set_lanes")
+
     def set_tile(self, slot: int, tile: int):
         check(self.lib.y3_net_set_tile(self._h, slot, tile), "y3_net_set_tile")
 
