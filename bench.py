@@ -21,6 +21,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (guides/MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 matrix peak (256 CU x 4096 FLOP/clk x 2.4 GHz; the ~5 PF figure is 2:1 sparse)
 
 
 def cpu_baseline(program, weights, anchors, image_size, budget_s=20.0):
@@ -52,6 +53,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per forward (y3_net_set_lanes)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="conv arithmetic: f32 (headline, fp32 MFMA) or bf16 (BASELINE config 5: bf16 MFMA, fp32 accumulate)")
     ap.add_argument("--graph", action="store_true", help="capture the per-batch pipeline in a HIP graph and replay it")
     ap.add_argument("--per-layer", action="store_true", help="also print the per-conv timing table to stderr")
     args = ap.parse_args()
@@ -80,7 +83,8 @@ def main():
     anchors = get_anchors(os.path.join(ROOT, "datasets/coco2012/anchors.txt")).astype(np.float32)
     net = runtime.Net(program)
     net.load_weights(weights)
-    net.plan(B, S)
+    from yolo_v3_tf2_amd import _lib as y3lib
+    net.plan(B, S, y3lib.Y3_DTYPE_BF16 if args.dtype == "bf16" else y3lib.Y3_DTYPE_F32)
     net.set_lanes(args.lanes)
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     images = torch.rand((B, S, S, 3), generator=gen, device="cuda", dtype=torch.float32)
@@ -148,6 +152,7 @@ def main():
     conv_ms_mean = sum(conv_ms) / len(conv_ms)
     flops_step = net.flops_per_image() * B
     achieved = flops_step / (conv_ms_mean * 1e-3) / 1e12
+    peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -162,17 +167,17 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic (uniform [0,1) images, seeded random-init weights; no checkpoint ships with the reference)",
-            "config": {"workload": f"full YOLOv3 detect, {B} images/GPU, {S}x{S}, 80 classes, fp32 MFMA conv, "
+            "config": {"workload": f"full YOLOv3 detect, {B} images/GPU, {S}x{S}, 80 classes, {'fp32' if args.dtype == 'f32' else 'bf16'} MFMA conv, "
                                    f"decode + class-agnostic NMS (max 100, iou 0.5, score 0.1), packed detections"
                                    + (", RCCL all-gather" if world > 1 else ""),
                        "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
                        "mean_num_valid": round(nv_mean, 2)},
             "roofline": {
-                "bound": "mfma", "kernel": "conv stack (74 x conv_f32_mfma launches + 1 first-layer conv per step)",
-                "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "bound": "mfma", "kernel": f"conv stack (74 x conv_{args.dtype}_mfma launches + 1 first-layer conv per step)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
                 "flops_per_launch": flops_step, "ms_per_launch": round(conv_ms_mean, 3),
                 "ms_median": round(conv_ms[len(conv_ms) // 2], 3),
             },

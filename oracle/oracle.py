@@ -119,11 +119,27 @@ def concat(a, b):
 
 
 # ---------------------------------------------------------------------------- network
-def forward(program, weights, images, acc64=False, keep=None):
+def round_bf16(a):
+    """fp32 -> bf16 (round to nearest even) -> fp32, NumPy."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def forward(program, weights, images, acc64=False, keep=None, bf16=False):
     """Run the node-level graph.  images [B,S,S,3] fp32.  Returns the head grids
     [[B,g,g,3,5+nc] x 3] (reference: core/parse_model.py:279-314 outputs).
     `keep`: optional set of tensor ids whose values are also returned (dict) for layer tests."""
     vals = {program.input_tensor: _c(images)}
+    if bf16:
+        from yolo_v3_tf2_amd.graph import ConvOp
+        materialised = {o.dst for o in program.ops if isinstance(o, ConvOp)} - set(program.outputs)
+        weights = dict(weights)
+        for n in program.conv_nodes:
+            if program.tensors[n.inputs[0]].channels != 3:
+                weights[f"conv{n.conv_index}.w"] = round_bf16(weights[f"conv{n.conv_index}.w"])
+        if program.tensors[program.input_tensor].channels != 3:
+            vals[program.input_tensor] = round_bf16(vals[program.input_tensor])
     last_use = {}
     for idx, n in enumerate(program.nodes):
         for i in n.inputs:
@@ -149,6 +165,8 @@ def forward(program, weights, images, acc64=False, keep=None):
             y = x.reshape(B, g, g2, 3, ch // 3)  # Reshape((g,g,3,5+nc)), core/parse_model.py:209-210
         else:
             raise ValueError(n.kind)
+        if bf16 and n.output in materialised:
+            y = round_bf16(y)
         vals[n.output] = y
         if n.output in keep:
             kept[n.output] = y

@@ -105,6 +105,112 @@ def test_upsample_concat_fused_conv(rt, program, weights):
         assert np.abs(g - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
 
 
+# ---------------------------------------------------------------------------------------------- bf16 (config 5)
+BF16_CASES = [
+    (64, 16, 3, [], [dict(filters=128, size=3, stride=2), dict(filters=128, size=3), dict(filters=255, size=1, bn=False, act="linear")]),
+    (128, 13, 2, [dict(filters=64, size=1), dict(filters=128, size=3, shortcut=-3)],
+     [dict(filters=256, size=3), dict(filters=64, size=1), dict(filters=32, size=1)]),
+    (32, 32, 2, [], [dict(filters=64, size=3, stride=2), dict(filters=64, size=3), dict(filters=64, size=1)]),
+    (3, 32, 2, [dict(filters=32, size=3)], [dict(filters=64, size=3, stride=2), dict(filters=64, size=3), dict(filters=64, size=1)]),
+]
+
+
+def _bf16_ulp(x):
+    return 2.0 ** -8 * max(1.0, float(np.abs(x).max()))
+
+
+@pytest.mark.parametrize("case", range(len(BF16_CASES)))
+def test_bf16_conv_layers_match_bf16_oracle(rt, case):
+    """bf16 MFMA conv vs the oracle run with the same roundings (bf16 weights/activations, fp32 arithmetic).
+    Tolerance: 1 bf16 ulp of the output's magnitude (a different fp32 summation order can flip a final rounding);
+    head outputs (fp32) are held to 2e-4 relative."""
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    in_ch, S, B, chain, heads = BF16_CASES[case]
+    p = mini_program(in_ch, chain, heads)
+    w = synthetic_weights(p, seed=200 + case)
+    rng = np.random.default_rng(case)
+    x = (rng.standard_normal((B, S, S, in_ch)) if in_ch != 3 else rng.random((B, S, S, in_ch))).astype(np.float32)
+    ref = O.forward(p, w, x, bf16=True)
+    net = rt.Net(p)
+    net.load_weights(w)
+    net.plan(B, S, _lib.Y3_DTYPE_BF16)
+    xin = _cuda(x) if in_ch == 3 else _cuda(O.round_bf16(x)).to(torch.bfloat16)
+    got = net.forward(xin)
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        g = g.cpu().numpy().reshape(r.shape)
+        assert np.abs(g - r).max() <= 2e-4 * max(1.0, float(np.abs(r).max())), (case, float(np.abs(g - r).max()))
+
+
+@pytest.mark.parametrize("tile", range(8))
+def test_bf16_every_tile(rt, tile):
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    bm, bn, _, bk = _lib.TILES_BF16[tile]
+    cin = 32 if bk == 32 else 64
+    p = mini_program(cin, [], [dict(filters=bn, size=3), dict(filters=bn, size=1), dict(filters=bn, size=3, stride=2)])
+    w = synthetic_weights(p, seed=8)
+    x = O.round_bf16(np.random.default_rng(8).standard_normal((3, 14, 14, cin)).astype(np.float32))
+    ref = O.forward(p, w, x, bf16=True)
+    net = rt.Net(p)
+    net.load_weights(w)
+    for slot in range(3):
+        net.set_tile_bf16(slot, tile)
+    net.plan(3, 14, _lib.Y3_DTYPE_BF16)
+    got = net.forward(_cuda(x).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        assert np.abs(g.cpu().numpy().reshape(r.shape) - r).max() <= 2e-4 * max(1.0, float(np.abs(r).max()))
+
+
+def test_bf16_intermediate_tensors_within_one_ulp(rt, program, weights):
+    """Intermediate bf16 activations (after residual adds / the fused upsample+concat conv) vs the bf16 oracle."""
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    S, B = 64, 2
+    x = np.random.default_rng(3).random((B, S, S, 3), dtype=np.float32)
+    ops = program.conv_ops()
+    probe = [ops[0].dst, ops[3].dst, ops[8].dst, ops[25].dst] + [o.dst for o in ops if o.src1 >= 0]
+    _, kept = O.forward(program, weights, x, keep=set(probe), bf16=True)
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.keep_activations(True)
+    net.plan(B, S, _lib.Y3_DTYPE_BF16)
+    net.forward(_cuda(x))
+    for t in probe:
+        g = net.read_tensor(t, B).cpu().numpy()
+        r = kept[t]
+        bad = np.abs(g - r) > 2 * _bf16_ulp(r)          # a flipped rounding upstream moves a value by <= 1-2 ulp
+        assert bad.mean() < 1e-3, (t, float(bad.mean()), float(np.abs(g - r).max()))
+
+
+def test_bf16_network_deviation_is_reported(rt, program, weights, anchors):
+    """Full network in bf16 vs (a) the bf16-emulating oracle (kernel correctness) and (b) the fp32 oracle (what bf16
+    costs).  The 1e-4 box bar of north_star is an fp32 statement; bf16 deviations are measured and bounded here."""
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    S, B = 96, 2
+    x = np.random.default_rng(1234).random((B, S, S, 3), dtype=np.float32)
+    ref16 = O.forward(program, weights, x, bf16=True)
+    ref32 = O.forward(program, weights, x)
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(B, S, _lib.Y3_DTYPE_BF16)
+    got = [g.cpu().numpy() for g in net.forward(_cuda(x))]
+    d16 = max(float(np.abs(g - r).max()) for g, r in zip(got, ref16))
+    d32 = max(float(np.abs(g - r).max()) for g, r in zip(got, ref32))
+    rel16 = max(float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(got, ref16))
+    rel32 = max(float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(got, ref32))
+    print(f"bf16 head logits: vs bf16-oracle max {d16:.3e} rel {rel16:.3e}; vs fp32-oracle max {d32:.3e} rel {rel32:.3e}")
+    assert rel16 < 1.5e-2 and d16 < 0.15         # summation-order rounding flips only
+    assert rel32 < 3e-2 and d32 < 0.5          # bf16 quantisation through 75 layers
+
+
 # ---------------------------------------------------------------------------------------------- network
 @pytest.mark.parametrize("S,B", [(96, 2), (160, 1)])
 def test_network_grids_match_oracle(rt, program, weights, S, B):

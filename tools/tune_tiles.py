@@ -24,33 +24,40 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--tiles", type=str, default=",".join(str(i) for i in range(len(TILES))))
+    ap.add_argument("--tiles", type=str, default="all")
     ap.add_argument("--write", type=str, default="")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     a = ap.parse_args()
     B, S = a.batch, a.image_size
     p = load_program(os.path.join(ROOT, "config/models/yolov3/model.yaml"), 80)
     w = synthetic_weights(p)
     net = runtime.Net(p)
     net.load_weights(w)
-    net.plan(B, S)
+    from yolo_v3_tf2_amd import _lib
+    bf = a.dtype == "bf16"
+    net.plan(B, S, _lib.Y3_DTYPE_BF16 if bf else _lib.Y3_DTYPE_F32)
     x = torch.rand((B, S, S, 3), device="cuda")
-    tiles = [int(t) for t in a.tiles.split(",")]
+    TL = _lib.TILES_BF16 if bf else TILES
+    TN_ = [f"{bm}x{bn}w{w}k{k}" for bm, bn, w, k in TL] if bf else TILE_NAMES
+    tiles = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else list(range(len(TL)))
     res = {}
     for t in [-1] + tiles:
-        bn = TILES[t][1] if t >= 0 else 0
+        bn = TL[t][1] if t >= 0 else 0
         ok = []
         for slot, o in enumerate(net.conv_ops):
             cp = (o.cout + 31) // 32 * 32
-            legal = t < 0 or (o.cin != 3 and cp % bn == 0 and not (t >= 20 and o.src1 >= 0))
+            legal = t < 0 or (o.cin != 3 and cp % bn == 0 and not (not bf and t >= 20 and o.src1 >= 0))
+            if bf and t >= 0:
+                legal = legal and o.cin % TL[t][3] == 0 and (o.src1 < 0 or o.c0 % TL[t][3] == 0)
             ok.append(legal)
-            net.set_tile(slot, t if legal else -1)
+            (net.set_tile_bf16 if bf else net.set_tile)(slot, t if legal else -1)
         best = None
         for _ in range(a.reps):
             ms = net.profile_convs(x)
             best = ms if best is None else np.minimum(best, ms)
         res[t] = (best, ok)
     names = {-1: "heur"}
-    names.update({t: TILE_NAMES[t] for t in tiles})
+    names.update({t: TN_[t] for t in tiles})
     print("conv  shape                      " + " ".join(f"{names[t]:>11s}" for t in res))
     winners = {}
     tot_best = tot_heur = 0.0

@@ -24,6 +24,9 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
          (64, 128, 4, 1), (64, 128, 4, 1), (64, 128, 4, 1),  # 20..22: timing-only probes (wrong results)
          (128, 128, 4, 1), (128, 128, 4, 1)]                # 23/24: 128x128 within 3 / 4 waves per SIMD of registers
 N_REAL_TILES = 20
+# bf16 kernel tiles: (BM, BN, waves, BK)
+TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
+              (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64)]
 TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" for bm, bn, w, st in TILES]
 
 
@@ -58,6 +61,7 @@ SYMBOLS = {
     "y3_net_destroy": (None, [_vp]),
     "y3_net_set_conv_weights": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f]),
     "y3_net_set_tile": (_i, [_vp, _i, _i]),
+    "y3_net_set_tile_bf16": (_i, [_vp, _i, _i]),
     "y3_net_keep_activations": (_i, [_vp, _i]),
     "y3_net_set_lanes": (_i, [_vp, _i]),
     "y3_net_plan": (_i, [_vp, _i, _i, _i]),

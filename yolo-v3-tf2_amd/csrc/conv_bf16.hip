@@ -1,0 +1,404 @@
+// bf16 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate.
+//
+// BASELINE config 5 ("bf16 MFMA fused conv+BN+LeakyReLU"): same fused op as conv_f32.hip
+// (reference: core/parse_model.py:27-52,72,134,155-156) with bf16 activations/weights in HBM and LDS.
+//   * activations NHWC bf16, weights packed [CoutPad][K] bf16 (k = tap*Cin + c), head outputs fp32;
+//   * K tile = BK bf16 (BK = 64: one 128-B line per row; BK = 32 for the two Cin = 32 layers); LDS rows are
+//     2*BK + 16 bytes (odd number of 16-B slots -> conflict-free ds_read_b128 of 16 different rows), double buffered;
+//   * MFMA 32x32x16: lane (r = l & 31, h = l >> 5) feeds A[row r][k = 16s + 8h .. +7] as one ds_read_b128;
+//   * epilogue through LDS: accumulators (+scale/shift, leaky) are written as an fp32 [BM][BN+4] tile, then every
+//     thread converts 8 consecutive channels (+ bf16 residual) and issues ONE 16-byte store -> full 128-B lines.
+#include <type_traits>
+
+#include "y3_kernels.h"
+
+namespace y3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    const unsigned short a = __builtin_bit_cast(unsigned short, (__bf16)lo);
+    const unsigned short b = __builtin_bit_cast(unsigned short, (__bf16)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32>
+__global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
+{
+    constexpr int BM = 32 * TM * WR;
+    constexpr int BN = 32 * TN * WC;
+    constexpr int NT = 64 * WR * WC;
+    constexpr int LPR = BK / 8;      // lanes per row (16 B = 8 bf16 each)
+    constexpr int RP = NT / LPR;     // rows per load pass
+    constexpr int AP = BM / RP, BP = BN / RP;
+    static_assert(BM % RP == 0 && BN % RP == 0 && AP >= 1 && BP >= 1, "tile too small for the thread count");
+    constexpr int ROWB = 2 * BK + 16;              // LDS row bytes
+    constexpr int STAGE_B = (BM + BN) * ROWB;      // bytes per stage
+    constexpr int CROW = BN + 4;                   // floats per row of the epilogue tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tilesN = p.CoutPad / BN;
+    const int mt = logical / tilesN, nt = logical - mt * tilesN;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.src0), 0, p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(CONCAT ? p.src1 : p.src0), 0, CONCAT ? p.src1_bytes : p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wpk), 0, p.w_bytes, 0x00020000);
+    const unsigned OOB0 = p.src0_bytes, OOB1 = CONCAT ? p.src1_bytes : p.src0_bytes;
+
+    const int lrow = tid / LPR;
+    const int lchunk = (tid % LPR) * 8;  // first bf16 of this lane's 16-B piece inside the K tile
+    int aoff[AP];
+    int aoff1[CONCAT ? AP : 1];
+    int ahw[AP];
+    const int HoWo = p.Ho * p.Wo;
+    const int C1 = p.Cin - p.C0;
+    const int b0 = m0 / HoWo;
+    const int r0 = m0 - b0 * HoWo;
+    const int ho0 = r0 / p.Wo;
+    const int wo0 = r0 - ho0 * p.Wo;
+    const float rcpW = 1.0f / (float)p.Wo, rcpH = 1.0f / (float)p.Ho;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + i * RP + lrow;
+        const int x = wo0 + i * RP + lrow;
+        const int qx = (int)(((float)x + 0.5f) * rcpW);
+        const int wo = x - qx * p.Wo;
+        const int y = ho0 + qx;
+        const int qy = (int)(((float)y + 0.5f) * rcpH);
+        const int ho = y - qy * p.Ho;
+        const int b = b0 + qy;
+        if (CONCAT) {
+            const int H0 = p.up0 ? (p.H >> 1) : p.H, W0 = p.up0 ? (p.W >> 1) : p.W;
+            const int h0 = p.up0 ? (ho >> 1) : ho, w0 = p.up0 ? (wo >> 1) : wo;
+            aoff[i] = ((b * H0 + h0) * W0 + w0) * p.C0;
+            aoff1[i] = ((b * p.H + ho) * p.W + wo) * C1;
+            ahw[i] = (m < p.M) ? 0 : (int)0x80000000;
+        } else {
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            aoff[i] = ((b * p.H + hi0) * p.W + wi0) * p.Cin;
+            ahw[i] = (m < p.M) ? ((hi0 << 16) | (wi0 & 0xffff)) : (int)0x80000000;
+        }
+    }
+    unsigned boff[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * RP + lrow) * p.K + lchunk) * 2);
+
+    int tap = 0, c0 = 0;
+    unsigned avoff[AP];
+    unsigned avoff1[CONCAT ? AP : 1];
+    auto set_tap = [&]() {
+        if (CONCAT) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)((aoff[i] + lchunk) * 2);
+                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)((aoff1[i] + lchunk) * 2);
+            }
+        } else {
+            const int u = tap / p.ksize, v = tap - u * p.ksize;
+            const int toff = (u * p.W + v) * p.Cin + lchunk;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                avoff[i] = ok ? (unsigned)((aoff[i] + toff) * 2) : OOB0;
+            }
+        }
+    };
+    set_tap();
+
+    u32x4 ra[AP], rb[BP];
+    int kglob = 0;
+    auto fetch = [&]() {
+        if (CONCAT) {
+            if (c0 < p.C0) {
+#pragma unroll
+                for (int i = 0; i < AP; ++i) ra[i] = bload16(rs0, avoff[i], c0 * 2);
+            } else {
+#pragma unroll
+                for (int i = 0; i < AP; ++i) ra[i] = bload16(rs1, avoff1[i], (c0 - p.C0) * 2);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) ra[i] = bload16(rs0, avoff[i], c0 * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) rb[j] = bload16(rsw, boff[j], kglob * 2);
+        kglob += BK;
+        c0 += BK;
+        if (c0 == p.Cin) {
+            c0 = 0;
+            ++tap;
+            if (!CONCAT) set_tap();
+        }
+    };
+    auto stage = [&](int buf) {
+        unsigned char *sa = smem + buf * STAGE_B;
+        unsigned char *sb = sa + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<u32x4 *>(sa + (i * RP + lrow) * ROWB + lchunk * 2) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4 *>(sb + (j * RP + lrow) * ROWB + lchunk * 2) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int KT = p.K / BK;
+    fetch();
+    stage(0);
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int a_frag = (wr * 32 * TM + fr) * ROWB + fh * 16;
+    const int b_frag = BM * ROWB + (wc * 32 * TN + fr) * ROWB + fh * 16;
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) fetch();
+        const unsigned char *sa = smem + cur * STAGE_B + a_frag;
+        const unsigned char *sb = smem + cur * STAGE_B + b_frag;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(sa + i * 32 * ROWB + s * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(sb + j * 32 * ROWB + s * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS ---------------------------------------------------------------------------
+    float *C = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = (wc * TN + j) * 32 + fr;
+        const float sc = p.scale[n0 + nl], sh = p.shift[n0 + nl];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ml = (wr * TM + i) * 32 + 4 * fh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] * sc + sh;
+                if (p.leaky) v = fmaxf(v, 0.1f * v);
+                C[(ml + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (OUT_F32) {
+        float *dst = static_cast<float *>(p.dst);
+        for (int idx = tid; idx < BM * BN; idx += NT) {
+            const int row = idx / BN, col = idx - row * BN;
+            const int m = m0 + row, n = n0 + col;
+            if (m < p.M && n < p.Cout) dst[(size_t)m * p.Cout + n] = C[row * CROW + col];
+        }
+    } else {
+        constexpr int PPR = BN / 8;  // 16-byte pieces (8 bf16) per row
+        unsigned short *dst = static_cast<unsigned short *>(p.dst);
+        const unsigned short *res = static_cast<const unsigned short *>(p.residual);
+        for (int pc = tid; pc < BM * PPR; pc += NT) {
+            const int row = pc / PPR, ch = (pc - row * PPR) * 8;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(C + row * CROW + ch);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(C + row * CROW + ch + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const size_t o = (size_t)m * p.Cout + n0 + ch;
+            if (res) {
+                const u32x4 rr = *reinterpret_cast<const u32x4 *>(res + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[2 * k] = __uint_as_float(rr[k] << 16) + v[2 * k];
+                    v[2 * k + 1] = __uint_as_float(rr[k] & 0xffff0000u) + v[2 * k + 1];
+                }
+            }
+            u32x4 out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
+            *reinterpret_cast<u32x4 *>(dst + o) = out;
+        }
+    }
+}
+
+// tile table of the bf16 kernel: {BM, BN, waves, BK}
+static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
+    {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 32, 4, 64},
+    {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 64},
+};
+
+TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < BF16_TILE_COUNT) ? tile : 0]; }
+
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32>
+static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
+{
+    constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
+    const size_t stages = 2 * (size_t)(BM + BN) * (2 * BK + 16);
+    const size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
+    const size_t lds = stages > ctile ? stages : ctile;
+    auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int TM, int TN, int WR, int WC, int BK>
+static hipError_t launch_tb(const ConvArgs &a, bool out_f32, hipStream_t s)
+{
+    if (a.src1)
+        return out_f32 ? launch_kb<TM, TN, WR, WC, BK, true, true>(a, s) : launch_kb<TM, TN, WR, WC, BK, true, false>(a, s);
+    return out_f32 ? launch_kb<TM, TN, WR, WC, BK, false, true>(a, s) : launch_kb<TM, TN, WR, WC, BK, false, false>(a, s);
+}
+
+hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
+{
+    if (tile < 0 || tile >= BF16_TILE_COUNT) return hipErrorInvalidValue;
+    const TileInfo t = kTilesBf16[tile];
+    if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
+    switch (tile) {
+        case 0: return launch_tb<2, 2, 2, 2, 64>(a, out_f32, s);
+        case 1: return launch_tb<2, 2, 4, 2, 64>(a, out_f32, s);
+        case 2: return launch_tb<2, 1, 2, 2, 64>(a, out_f32, s);
+        case 3: return launch_tb<1, 1, 2, 2, 64>(a, out_f32, s);
+        case 4: return launch_tb<1, 1, 4, 1, 64>(a, out_f32, s);
+        case 5: return launch_tb<2, 1, 2, 2, 32>(a, out_f32, s);
+        case 6: return launch_tb<1, 1, 2, 2, 32>(a, out_f32, s);
+        case 7: return launch_tb<1, 2, 2, 2, 64>(a, out_f32, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// First layer in bf16 mode: fp32 image in, fp32 arithmetic (K = 27), bf16 out.  Same structure as
+// conv_first_f32; the LDS transpose lets 4 lanes write one pixel's 32 bf16 channels (64 B) as 16-B stores.
+// ---------------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_first_bf16(const ConvArgs p, const float *__restrict__ w)
+{
+    constexpr int ROW = COUT + 4;
+    __shared__ __attribute__((aligned(16))) float tr[4][64 * ROW];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int mw = blockIdx.x * 256 + wave * 64;
+    const int m = mw + lane;
+    const int HW = p.H * p.W;
+    const bool live = m < p.M;
+    const int mm = live ? m : 0;
+    const int b = mm / HW;
+    const int r = mm - b * HW;
+    const int ho = r / p.W, wo = r - ho * p.W;
+    const float *x = static_cast<const float *>(p.src0);
+    float acc[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
+#pragma unroll 1
+    for (int u = 0; u < 3; ++u) {
+        const int hi = ho - 1 + u;
+#pragma unroll 1
+        for (int v = 0; v < 3; ++v) {
+            const int wi = wo - 1 + v;
+            const bool ok = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float *xp = x + ((size_t)(b * p.H + (ok ? hi : 0)) * p.W + (ok ? wi : 0)) * 3;
+            float xv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xv[c] = ok ? xp[c] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *wr = w + ((u * 3 + v) * 3 + c) * COUT;
+#pragma unroll
+                for (int n = 0; n < COUT; ++n) acc[n] += xv[c] * wr[n];
+            }
+        }
+    }
+    float *t = tr[wave];
+#pragma unroll
+    for (int n = 0; n < COUT; n += 4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[n + e] * p.scale[n + e] + p.shift[n + e];
+            if (p.leaky) v = fmaxf(v, 0.1f * v);
+            o[e] = v;
+        }
+        *reinterpret_cast<f32x4 *>(t + lane * ROW + n) = o;
+    }
+    unsigned short *dst = static_cast<unsigned short *>(p.dst);
+    constexpr int CH = COUT / 8;   // 16-B pieces (8 bf16) per pixel
+    constexpr int PPI = 64 / CH;   // pixels per store instruction
+    const int c8 = lane % CH, pl = lane / CH;
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+        const int px = it * PPI + pl;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(t + px * ROW + c8 * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(t + px * ROW + c8 * 8 + 4);
+        u32x4 o;
+        o[0] = pack_bf16(v0[0], v0[1]);
+        o[1] = pack_bf16(v0[2], v0[3]);
+        o[2] = pack_bf16(v1[0], v1[1]);
+        o[3] = pack_bf16(v1[2], v1[3]);
+        if (mw + px < p.M) *reinterpret_cast<u32x4 *>(dst + (size_t)(mw + px) * COUT + c8 * 8) = o;
+    }
+}
+
+hipError_t launch_conv_first_bf16(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s)
+{
+    if (a.Cin != 3 || a.ksize != 3 || a.stride != 1 || a.Cout != 32 || a.residual || a.src1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv_first_bf16<32>, dim3((a.M + 255) / 256), dim3(256), 0, s, a, w_hwio_dev);
+    return hipGetLastError();
+}
+
+// bf16 -> fp32 copy (y3_net_read_tensor in bf16 mode)
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const unsigned short *x, float *y, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = __uint_as_float((unsigned)x[i] << 16);
+}
+
+hipError_t launch_bf16_to_f32(const void *x, float *y, size_t n, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s,
+                       static_cast<const unsigned short *>(x), y, n);
+    return hipGetLastError();
+}
+
+}  // namespace y3

@@ -45,7 +45,9 @@ struct ConvSlot {
     int cout_pad = 0;
     int K = 0;
     int tile = -1;             // -1: choose by heuristic at plan time
+    int tile_bf16 = -1;
     float *w_dev = nullptr;    // packed [CoutPad][K] (or HWIO for the first layer)
+    void *wbf_dev = nullptr;   // same, bf16 (not for the first layer)
     float *scale_dev = nullptr;
     float *shift_dev = nullptr;
 };
@@ -90,6 +92,38 @@ void free_plan(y3_net *n)
     for (void *p : n->blocks) (void)hipFree(p);
     n->blocks.clear();
     n->tdev.assign(n->tensors.size(), nullptr);
+}
+
+unsigned short f32_to_bf16_rne(float f)
+{
+    unsigned u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+int choose_tile_bf16(const ConvSlot &c, long long M)
+{
+    std::vector<int> cand;
+    if (c.d.cin % 64)
+        cand = {5, 6};                       // BK = 32 (Cin = 32 layers, Cout = 64)
+    else if (c.cout_pad % 128 == 0)
+        cand = {0, 7, 3};
+    else if (c.cout_pad % 64 == 0)
+        cand = {2, 3};
+    else
+        cand = {4};
+    int best = cand.back();
+    for (int t : cand) {
+        y3::TileInfo s = y3::conv_bf16_tile_info(t);
+        if (c.cout_pad % s.bn) continue;
+        long long blocks = ((M + s.bm - 1) / s.bm) * (c.cout_pad / s.bn);
+        if (blocks >= 512) {
+            best = t;
+            break;
+        }
+    }
+    return best;
 }
 
 int choose_tile(const ConvSlot &c, long long M)
@@ -206,6 +240,7 @@ void y3_net_destroy(y3_net *net)
     }
     for (ConvSlot &c : net->convs) {
         if (c.w_dev) (void)hipFree(c.w_dev);
+        if (c.wbf_dev) (void)hipFree(c.wbf_dev);
         if (c.scale_dev) (void)hipFree(c.scale_dev);
         if (c.shift_dev) (void)hipFree(c.shift_dev);
     }
@@ -246,6 +281,12 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
     if (!c.scale_dev) HIP_TRY(hipMalloc(&c.scale_dev, CP * sizeof(float)));
     if (!c.shift_dev) HIP_TRY(hipMalloc(&c.shift_dev, CP * sizeof(float)));
     HIP_TRY(hipMemcpy(c.w_dev, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!c.first_layer) {
+        std::vector<unsigned short> pb(pk.size());
+        for (size_t i = 0; i < pk.size(); ++i) pb[i] = f32_to_bf16_rne(pk[i]);
+        if (!c.wbf_dev) HIP_TRY(hipMalloc(&c.wbf_dev, pb.size() * sizeof(unsigned short)));
+        HIP_TRY(hipMemcpy(c.wbf_dev, pb.data(), pb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(c.scale_dev, scale.data(), CP * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c.shift_dev, shift.data(), CP * sizeof(float), hipMemcpyHostToDevice));
     c.loaded = true;
@@ -262,6 +303,20 @@ y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
         if (c.first_layer || c.cout_pad % s.bn) return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile does not divide Cout");
     }
     c.tile = tile;
+    return Y3_OK;
+}
+
+y3_status y3_net_set_tile_bf16(y3_net *net, int slot, int tile)
+{
+    if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::BF16_TILE_COUNT)
+        return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: bad argument");
+    ConvSlot &c = net->convs[slot];
+    if (tile >= 0) {
+        y3::TileInfo s = y3::conv_bf16_tile_info(tile);
+        if (c.first_layer || c.cout_pad % s.bn || c.d.cin % s.stages || (c.d.src1 >= 0 && c.d.c0 % s.stages))
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile does not fit this conv");
+    }
+    c.tile_bf16 = tile;
     return Y3_OK;
 }
 
@@ -282,7 +337,7 @@ y3_status y3_net_keep_activations(y3_net *net, int keep)
 y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
 {
     if (!net || max_batch <= 0 || image_size <= 0) return fail(Y3_ERR_INVALID, "y3_net_plan: bad argument");
-    if (dtype != Y3_DTYPE_F32) return fail(Y3_ERR_INVALID, "y3_net_plan: only Y3_DTYPE_F32 is implemented");
+    if (dtype != Y3_DTYPE_F32 && dtype != Y3_DTYPE_BF16) return fail(Y3_ERR_INVALID, "y3_net_plan: unknown dtype %d", dtype);
     for (const y3_tensor_desc &t : net->tensors)
         if (t.div <= 0 || image_size % t.div) return fail(Y3_ERR_INVALID, "y3_net_plan: image_size %d not divisible by %d", image_size, t.div);
     HIP_TRY(hipSetDevice(net->device));
@@ -310,7 +365,7 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
     }
     for (int t = 0; t < nt; ++t) {
         const int s = image_size / net->tensors[t].div;
-        net->tbytes[t] = (size_t)max_batch * s * s * net->tensors[t].channels * sizeof(float);
+        net->tbytes[t] = (size_t)max_batch * s * s * net->tensors[t].channels * (dtype == Y3_DTYPE_BF16 ? 2 : 4);
         if (net->tbytes[t] >= 0xFFFFFFF0ull && first[t] >= 0)
             return fail(Y3_ERR_INVALID, "y3_net_plan: tensor %d is %zu bytes; 32-bit buffer offsets need < 4 GiB, lower max_batch", t, net->tbytes[t]);
     }
@@ -367,13 +422,22 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
         const int sp = spatial(net, t);
         return (size_t)sp * sp * net->tensors[t].channels;
     };
+    const bool bf = net->dtype == Y3_DTYPE_BF16;
+    auto is_out = [&](int t) { return t == net->outputs[0] || t == net->outputs[1] || t == net->outputs[2]; };
+    // element size: head grids are always fp32; the image batch is fp32 when the Cin = 3 first-layer kernel reads it
+    // (a model whose input feeds an MFMA conv directly hands bf16 in bf16 mode); everything else follows the plan
+    auto esz = [&](int t) -> size_t {
+        if (is_out(t)) return 4;
+        if (t == net->input_tensor) return (bf && net->tensors[t].channels != 3) ? 2 : 4;
+        return bf ? 2 : 4;
+    };
     auto ptr = [&](int t) -> void * {
         if (t < 0) return nullptr;
-        float *base = nullptr;
-        if (t == net->input_tensor) base = const_cast<float *>(images);
+        char *base = nullptr;
+        if (t == net->input_tensor) base = reinterpret_cast<char *>(const_cast<float *>(images));
         for (int i = 0; i < 3 && !base; ++i)
-            if (t == net->outputs[i]) base = grids[i];
-        if (base) return base + (size_t)b0 * img_elems(t);
+            if (t == net->outputs[i]) base = reinterpret_cast<char *>(grids[i]);
+        if (base) return base + (size_t)b0 * img_elems(t) * esz(t);
         // arena tensors share blocks with other (dead) tensors of different per-image size: give every lane its
         // own 1/lanes region of the block so that concurrent sub-batches never alias
         char *blk = static_cast<char *>(net->tdev[t]);
@@ -381,7 +445,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
         const size_t region = (net->tblock[t] / lanes + 255) & ~(size_t)255;  // blocks carry 4 KiB of slack
         return blk + (size_t)lane * region;
     };
-    auto bytes = [&](int t) -> size_t { return (size_t)nb * img_elems(t) * sizeof(float); };
+    auto bytes = [&](int t) -> size_t { return (size_t)nb * img_elems(t) * esz(t); };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ms_out) {
         HIP_TRY(hipEventCreate(&ev0));
@@ -420,7 +484,17 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
             hipError_t e;
-            if (c.first_layer) {
+            if (bf && c.first_layer) {
+                if (is_out(d.dst)) return fail(Y3_ERR_INVALID, "conv %d: first layer cannot be a head in bf16 mode", o.index);
+                e = y3::launch_conv_first_bf16(a, c.w_dev, s);
+            } else if (bf) {
+                a.wpk = c.wbf_dev;
+                a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * 2);
+                const bool out_f32 = is_out(d.dst);
+                if (d.residual >= 0 && out_f32) return fail(Y3_ERR_INVALID, "conv %d: residual on a head output is not supported in bf16 mode", o.index);
+                const int tile = c.tile_bf16 >= 0 ? c.tile_bf16 : choose_tile_bf16(c, a.M);
+                e = y3::launch_conv_bf16(a, tile, out_f32, s);
+            } else if (c.first_layer) {
                 e = y3::launch_conv_first_f32(a, c.w_dev, s);
             } else {
                 const int tile = c.tile >= 0 ? c.tile : choose_tile(c, a.M);
@@ -435,6 +509,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 if (o.index < n_ms) ms_out[o.index] = ms;
             }
         } else {
+            if (bf) return fail(Y3_ERR_INVALID, "stand-alone add/upsample/concat ops are fp32 only");
             const y3_aux_desc &x = net->aux[o.index];
             const int sp = spatial(net, x.dst);
             const int C = net->tensors[x.dst].channels;
@@ -525,6 +600,11 @@ y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size
     if (n_elems) *n_elems = n;
     if (!dst_dev) return Y3_OK;
     if (!net->tdev[t]) return fail(Y3_ERR_STATE, "y3_net_read_tensor: tensor %d is not held in the arena", t);
+    if (net->dtype == Y3_DTYPE_BF16) {
+        hipError_t e = y3::launch_bf16_to_f32(net->tdev[t], dst_dev, n, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_read_tensor: %s", hipGetErrorString(e));
+        return Y3_OK;
+    }
     HIP_TRY(hipMemcpyAsync(dst_dev, net->tdev[t], n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return Y3_OK;
 }

@@ -37,6 +37,13 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
 // first layer: 3x3 stride-1 conv with Cin=3 (direct, VALU)
 hipError_t launch_conv_first_f32(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
 
+// bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
+static constexpr int BF16_TILE_COUNT = 8;
+TileInfo conv_bf16_tile_info(int tile);
+hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);
+hipError_t launch_conv_first_bf16(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
+hipError_t launch_bf16_to_f32(const void *x, float *y, size_t n, hipStream_t s);
+
 hipError_t launch_add(const float *a, const float *b, float *y, size_t n, hipStream_t s);
 hipError_t launch_upsample2x(const float *x, int B, int H, int W, int C, float *y, hipStream_t s);
 hipError_t launch_concat(const float *a, int Ca, const float *b, int Cb, size_t npix, float *y, hipStream_t s);

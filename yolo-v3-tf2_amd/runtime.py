@@ -67,6 +67,7 @@ class Net:
                                      p.input_tensor, outs, p.nclasses, C.byref(self._h)), "y3_net_create")
         self.image_size = 0
         self.max_batch = 0
+        self.dtype = _lib.Y3_DTYPE_F32
         self.weights_loaded = False
 
     def __del__(self):
@@ -103,9 +104,15 @@ class Net:
     def set_tile(self, slot: int, tile: int):
         check(self.lib.y3_net_set_tile(self._h, slot, tile), "y3_net_set_tile")
 
-    def plan(self, max_batch: int, image_size: int, dtype: int = _lib.Y3_DTYPE_F32):
+    def set_tile_bf16(self, slot: int, tile: int):
+        check(self.lib.y3_net_set_tile_bf16(self._h, slot, tile), "y3_net_set_tile_bf16")
+
+    def plan(self, max_batch: int, image_size: int, dtype: Optional[int] = None):
+        """dtype: _lib.Y3_DTYPE_F32 (default) or _lib.Y3_DTYPE_BF16 (bf16 activations/weights, fp32 accumulate)."""
+        if dtype is None:
+            dtype = self.dtype
         check(self.lib.y3_net_plan(self._h, max_batch, image_size, dtype), "y3_net_plan")
-        self.max_batch, self.image_size = max_batch, image_size
+        self.max_batch, self.image_size, self.dtype = max_batch, image_size, dtype
 
     def grid_sizes(self, image_size=None):
         s = image_size or self.image_size
@@ -115,8 +122,10 @@ class Net:
         """images [B,S,S,3] fp32 on the GPU -> [grid13, grid26, grid52], each [B,g,g,3,5+nc]."""
         _need_cuda(images)
         cin = self.program.tensors[self.program.input_tensor].channels
-        if images.dtype != torch.float32 or images.dim() != 4 or images.shape[3] != cin or images.shape[1] != images.shape[2]:
-            raise Y3Error(f"images must be float32 [B,S,S,{cin}]")
+        # bf16 plan + an input that feeds an MFMA conv directly (layer tests): the input is bf16 as well
+        want = torch.bfloat16 if (self.dtype == _lib.Y3_DTYPE_BF16 and cin != 3) else torch.float32
+        if images.dtype != want or images.dim() != 4 or images.shape[3] != cin or images.shape[1] != images.shape[2]:
+            raise Y3Error(f"images must be {want} [B,S,S,{cin}]")
         B, S = images.shape[0], images.shape[1]
         if S != self.image_size or B > self.max_batch:
             self.plan(max(B, self.max_batch), S)
