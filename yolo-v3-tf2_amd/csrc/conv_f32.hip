@@ -38,6 +38,7 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 
 // PROBE != 0 builds timing-only ablations of the main loop (wrong results; tools/tune_tiles.py --probe):
 //   1: LDS fragment reads + MFMA only   2: 1 + the two barriers   3: 2 + global fetches (never staged)
+//   4: MFMA + barriers only (fragments read from LDS once, before the loop)
 template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvArgs p)
 {
@@ -198,6 +199,13 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     const int a_frag = (wr * 32 * TM + fr) * LDS_ROW + fh * 4;
     const int b_frag = BM * LDS_ROW + (wc * 32 * TN + fr) * LDS_ROW + fh * 4;
 
+    f32x4 pfa[TM], pfb[TN];
+    if (PROBE == 4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) pfa[i] = *reinterpret_cast<const f32x4 *>(smem + a_frag + i * 32 * LDS_ROW);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) pfb[j] = *reinterpret_cast<const f32x4 *>(smem + b_frag + j * 32 * LDS_ROW);
+    }
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = (STAGES == 2) ? (kt & 1) : 0;
         if (PROBE == 0 || PROBE == 3) {
@@ -208,10 +216,17 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 fa[TM], fb[TN];
+            if (PROBE == 4) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = pfa[i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = pfb[j];
+            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(sa + i * 32 * LDS_ROW + q * 8);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(sb + j * 32 * LDS_ROW + q * 8);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -311,6 +326,7 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {256, 128, 16, 1}, {128, 64, 8, 1}, {256, 64, 8, 1}, {128, 64, 8, 2},
     {64, 128, 4, 1}, {64, 128, 4, 1}, {64, 128, 4, 1},  // timing-only probes of tile 10 (wrong results)
     {128, 128, 4, 1}, {128, 128, 4, 1},                  // 128x128 with the register budget of 3 / 4 waves per SIMD
+    {64, 128, 4, 1},                                     // probe 4
 };
 
 TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUNT) ? tile : 0]; }
@@ -359,6 +375,7 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 20: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 1>(a, s);  // probes (64x128)
         case 21: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 2>(a, s);
         case 22: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 3>(a, s);
+        case 25: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 4>(a, s);
         case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 3>(a, s);
         case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 4>(a, s);
         default: return hipErrorInvalidValue;

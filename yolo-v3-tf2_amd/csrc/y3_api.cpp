@@ -74,6 +74,7 @@ struct y3_net {
     int max_batch = 0, image_size = 0, dtype = Y3_DTYPE_F32;
     int keep_all = 0;              // 1: no buffer reuse, every intermediate stays readable after a forward
     int lanes = 1;                 // sub-batches run concurrently on forked streams (y3_net_set_lanes)
+    int cur_batch = 1;             // batch of the forward being enqueued
     hipEvent_t fork_ev = nullptr;
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t join_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -442,8 +443,10 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
         // own 1/lanes region of the block so that concurrent sub-batches never alias
         char *blk = static_cast<char *>(net->tdev[t]);
         if (!blk) return nullptr;
-        const size_t region = (net->tblock[t] / lanes + 255) & ~(size_t)255;  // blocks carry 4 KiB of slack
-        return blk + (size_t)lane * region;
+        // lane regions start at the lane's first image (scaled to the block size), 256-B aligned; blocks carry 4 KiB of slack
+        const size_t off = ((size_t)((double)net->tblock[t] * b0 / net->cur_batch) + 255) & ~(size_t)255;
+        (void)lanes;
+        return blk + (lane ? off : 0);
     };
     auto bytes = [&](int t) -> size_t { return (size_t)nb * img_elems(t) * esz(t); };
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -548,8 +551,9 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
     if ((uintptr_t)images & 3) return fail(Y3_ERR_INVALID, "y3_net_forward: images not 4-byte aligned");
     // Images are independent, so the batch can run as `lanes` sub-batches on forked streams: while one sub-batch's
     // conv kernel drains (its last workgroups leave CUs under-occupied), the other sub-batch's kernel fills them.
+    net->cur_batch = batch;
     int lanes = (ms_out || net->lanes < 2) ? 1 : net->lanes;
-    while (lanes > 1 && (batch % lanes || batch / lanes < 1)) --lanes;
+    while (lanes > 1 && batch / lanes < 1) --lanes;
     if (lanes == 1) return run_slice(net, images, grids, 0, batch, s, ms_out, n_ms);
     HIP_TRY(hipSetDevice(net->device));
     if (!net->fork_ev) {
@@ -560,10 +564,15 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
         }
     }
     HIP_TRY(hipEventRecord(net->fork_ev, s));
-    const int nb = batch / lanes;
+    // unequal sub-batches on purpose (2 lanes: 3/8 and 5/8 of the batch): equal ones run the same kernels in lockstep,
+    // so their tails coincide and nothing fills them
+    int start[Y3_MAX_LANES + 1];
+    for (int l = 0; l <= lanes; ++l) start[l] = (int)((long long)batch * l / lanes);
+    if (lanes == 2 && batch >= 8) start[1] = batch * 3 / 8;
     for (int l = 0; l < lanes; ++l) {
+        const int nb = start[l + 1] - start[l];
         HIP_TRY(hipStreamWaitEvent(net->lane_stream[l], net->fork_ev, 0));
-        y3_status st = run_slice(net, images, grids, l * nb, nb, net->lane_stream[l], nullptr, 0, l, lanes);
+        y3_status st = run_slice(net, images, grids, start[l], nb, net->lane_stream[l], nullptr, 0, l, lanes);
         if (st != Y3_OK) return st;
         HIP_TRY(hipEventRecord(net->join_ev[l], net->lane_stream[l]));
         HIP_TRY(hipStreamWaitEvent(s, net->join_ev[l], 0));

@@ -113,6 +113,30 @@ class Net:
             dtype = self.dtype
         check(self.lib.y3_net_plan(self._h, max_batch, image_size, dtype), "y3_net_plan")
         self.max_batch, self.image_size, self.dtype = max_batch, image_size, dtype
+        self._apply_tuning()
+
+    @staticmethod
+    def conv_signature(o: ConvOp, image_size: int) -> str:
+        ho = image_size // o.out_div
+        return f"k{o.size}s{o.stride}_c{o.cin}_n{o.cout}_h{ho}_r{int(o.residual >= 0)}_u{int(o.src1 >= 0)}"
+
+    def _apply_tuning(self):
+        """Per-conv tile ids measured by tools/tune_tiles.py for this (dtype, batch, image size), if a table exists;
+        otherwise the library's heuristic stays in force."""
+        import json
+        import os
+        from . import PACKAGE_DIR
+        name = f"{'bf16' if self.dtype == _lib.Y3_DTYPE_BF16 else 'f32'}_b{self.max_batch}_s{self.image_size}.json"
+        path = os.path.join(PACKAGE_DIR, "tuning", name)
+        setter = self.set_tile_bf16 if self.dtype == _lib.Y3_DTYPE_BF16 else self.set_tile
+        table = {}
+        if os.path.exists(path) and not os.environ.get("Y3_NO_TUNING"):
+            with open(path) as f:
+                table = json.load(f).get("tiles", {})
+        for slot, o in enumerate(self.conv_ops):
+            if o.cin == 3:
+                continue
+            setter(slot, int(table.get(self.conv_signature(o, self.image_size), -1)))
 
     def grid_sizes(self, image_size=None):
         s = image_size or self.image_size
