@@ -154,6 +154,11 @@ def main():
     achieved = flops_step / (conv_ms_mean * 1e-3) / 1e12
     peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
 
+    traffic = None
+    tf_path = os.path.join(ROOT, "profiles", f"r01_traffic_{args.dtype}_b{B}_s{S}.json")
+    if os.path.exists(tf_path):   # PMC-derived HBM bytes per conv-stack pass, measured by tools/profile.sh on this workload
+        with open(tf_path) as f:
+            traffic = json.load(f).get("conv_stack_hbm_bytes_per_step")
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         line = {
@@ -177,7 +182,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": f"conv stack (74 x conv_{args.dtype}_mfma launches + 1 first-layer conv per step)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "flops_per_launch": flops_step, "ms_per_launch": round(conv_ms_mean, 3),
                 "ms_median": round(conv_ms[len(conv_ms) // 2], 3),
             },

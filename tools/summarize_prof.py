@@ -13,7 +13,16 @@ def short(name):
     if m:
         tm, tn, wr, wc, cat, st = map(int, m.groups())
         return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{st}{',cat' if cat else ''}>"
-    for k in ("conv_first_f32", "decode_kernel", "nms_kernel", "pack_kernel", "class_scores"):
+    m = re.search(r"conv_f32_mfma<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)", name)
+    if m:
+        tm, tn, wr, wc = (int(m.group(i)) for i in range(1, 5))
+        return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{m.group(6)}{',cat' if m.group(5) == 'true' else ''}>"
+    m = re.search(r"conv_bf16_mfma<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)", name)
+    if m:
+        tm, tn, wr, wc, bk = (int(m.group(i)) for i in range(1, 6))
+        return (f"conv_bf16_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},k{bk}{',cat' if m.group(6) == 'true' else ''}"
+                f"{',f32out' if m.group(7) == 'true' else ''}>")
+    for k in ("conv_first_f32", "conv_first_bf16", "decode_kernel", "nms_kernel", "pack_kernel", "class_scores"):
         if k in name:
             return k
     return name[:60]
@@ -75,6 +84,20 @@ def main(out):
                 hm = a.get("TCC_HIT_sum", 0) + a.get("TCC_MISS_sum", 0)
                 hit = a.get("TCC_HIT_sum", 0) / hm if hm else 0
                 o.write(f"{k:<52s} {n:>4d} {busy:9.3f} {occ:10.2f} {fetch:18.1f} {write:16.1f} {hit:7.3f}\n")
+    # HBM traffic of one conv-stack pass (all conv kernels of one step): FETCH_SIZE (KiB, x2 gfx950 correction) + WRITE_SIZE
+    if agg:
+        import json
+        conv = [k for k in agg if k.startswith("conv_")]
+        first = [k for k in conv if "first" in k]
+        steps = max(calls[k] for k in first) if first else 1
+        fetch = sum(agg[k].get("FETCH_SIZE", 0) for k in conv) * 1024 * 2 / steps
+        write = sum(agg[k].get("WRITE_SIZE", 0) for k in conv) * 1024 / steps
+        with open(os.path.join(out, "summary_traffic.json"), "w") as o:
+            json.dump({"steps_profiled": steps, "conv_stack_fetch_bytes_per_step": fetch,
+                       "conv_stack_write_bytes_per_step": write, "conv_stack_hbm_bytes_per_step": fetch + write,
+                       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled "
+                               "(gfx950 reports half of a wide coalesced stream), summed over the conv kernels of one step"},
+                      o, indent=1)
     for f in ("summary_kernel_stats.txt", "summary_derived.txt"):
         fp = os.path.join(out, f)
         if os.path.exists(fp):
