@@ -135,6 +135,15 @@ double y3_net_flops_per_image(const y3_net *net);
 y3_status y3_net_profile_convs(y3_net *net, const float *images_dev, int batch, float *ms_out, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Image input stage (the step right before the path): decode_image(channels=3, dtype=float32) + tf.image.resize
+ * (reference: inference.py:157-158).  image_dev: [height,width,channels] uint8 (is_uint8=1; converted with * 1/255) or
+ * float32 (is_uint8=0); channels 3 or 4 (alpha dropped).  Writes the bilinear (half-pixel centres, no antialias)
+ * resize to image_size x image_size into batch_dev[slot] of an NHWC fp32 batch [*,image_size,image_size,3].
+ * ---------------------------------------------------------------------------------------- */
+y3_status y3_preprocess_image(const void *image_dev, int is_uint8, int height, int width, int channels,
+                              float *batch_dev, int slot, int image_size, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * yolo_decode   (reference: core/yolo_decode_layer.py:15-36)
  * grids_dev[s]: [B,g_s,g_s,3,5+nc]; anchors_host: [3][3][2] normalised (w,h), scale s uses anchors[s].
  * Outputs [B,N,4], [B,N,1], [B,N,nc] with N = 3*sum g_s^2, scales concatenated in input order.

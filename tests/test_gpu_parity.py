@@ -437,6 +437,27 @@ def test_pack_detections(rt):
         assert not pb[b, n:].any() and not pc[b, n:].any()
 
 
+# ---------------------------------------------------------------------------------------------- image input
+@pytest.mark.parametrize("H,W,C,S", [(667, 812, 4, 416), (100, 37, 3, 64), (32, 32, 3, 96), (1080, 1920, 3, 608)])
+def test_preprocess_matches_host_restatement(rt, H, W, C, S):
+    """uint8 -> [0,1] -> bilinear resize on the GPU == the NumPy restatement of TF's kernel, bit for bit
+    (same fp32 operations in the same order, no contraction)."""
+    from yolo_v3_tf2_amd.core.utils import resize_bilinear
+    rng = np.random.default_rng(H)
+    img = rng.integers(0, 256, (H, W, C), dtype=np.uint8)
+    ref = resize_bilinear(img[..., :3].astype(np.float32) * np.float32(1.0 / 255.0), S, S)
+    batch = torch.zeros((2, S, S, 3), device="cuda")
+    rt.preprocess_image(_cuda(img), batch, 1)
+    torch.cuda.synchronize()
+    got = batch[1].cpu().numpy()
+    assert not batch[0].any()
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+    # float32 input path
+    f = rng.random((H, W, 3), dtype=np.float32)
+    rt.preprocess_image(_cuda(f), batch, 0)
+    assert np.array_equal(batch[0].cpu().numpy(), resize_bilinear(f, S, S))
+
+
 # ---------------------------------------------------------------------------------------------- end to end
 def test_end_to_end_detect(rt, program, weights, anchors):
     """image -> 5-tuple.  Two-stage bar: (i) NMS on the *device's own* boxes/scores is
@@ -462,3 +483,39 @@ def test_end_to_end_detect(rt, program, weights, anchors):
         near = np.abs(rs - 0.1).min()
         assert near < 1e-5, f"selection differs without a near-tie at the score threshold (closest {near})"
     assert np.array_equal(gc, rc) or np.abs(gs_ - rs).max() < 1e-4
+
+
+def test_inference_counterpart_config1(rt, program, weights, anchors, tmp_path):
+    """BASELINE config 1 (plumbing): the reference's YAML keys -> Inference()(**cfg) on one image file; detect.txt and
+    the gathered detections equal what the oracle produces from the same resized image."""
+    import os
+    import yaml
+    from oracle import oracle as O
+    from yolo_v3_tf2_amd.inference import Inference
+    from yolo_v3_tf2_amd.core.utils import load_image_rgb01, resize_bilinear
+    from yolo_v3_tf2_amd.weights import save_weights
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config/detect_config_coco.yaml")))
+    wpath = str(tmp_path / "w.safetensors")
+    save_weights(wpath, weights)
+    cfg.update(input_weights_path=wpath, output_dir=str(tmp_path / "out"),
+               model_config_file=os.path.join(root, cfg["model_config_file"]),
+               classes_name_file=os.path.join(root, cfg["classes_name_file"]),
+               anchors_file=os.path.join(root, cfg["anchors_file"]),
+               image_file_path=os.path.join(root, cfg["image_file_path"]), nms_score_threshold=0.05)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        results = Inference()(**cfg)
+    finally:
+        os.chdir(cwd)
+    assert len(results) == 1
+    bboxes, classes, scores, names = results[0]
+    lines = open(os.path.join(cfg["output_dir"], "detect.txt")).read().strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("[") and os.path.exists(os.path.join(cfg["output_dir"], "detect_0.jpg"))
+    img = resize_bilinear(load_image_rgb01(cfg["image_file_path"]), 416, 416)[None]
+    rb, rc, rs, rsel, rnv = O.detect(program, weights, img, anchors, 100, 0.5, 0.05)
+    ob, oc, os_ = O.gather_valid(rb[0], rc[0], rs[0], rsel[0], rnv[0])
+    assert len(bboxes) == len(ob) and np.array_equal(classes, oc)
+    assert np.abs(bboxes - ob).max() <= 1e-4 and np.abs(scores - os_).max() <= 1e-4
+    assert lines[0].count("%") == len(ob)

@@ -94,3 +94,25 @@ def test_shard_range_covers_batch():
             r = [shard_range(n, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert max(e - s for s, e in r) - min(e - s for s, e in r) <= 1
+
+
+def test_evaluate_detections_counters():
+    from yolo_v3_tf2_amd.evaluate_detections import EvaluateDetections
+    ev = EvaluateDetections(3, 0.5)
+    gt_b = np.array([[0.1, 0.1, 0.4, 0.4], [0.5, 0.5, 0.9, 0.9]], np.float32)
+    gt_c = np.array([0, 2])
+    pr_b = np.array([[0.1, 0.1, 0.4, 0.41],      # TP for gt 0
+                     [0.11, 0.1, 0.4, 0.4],      # same gt again: the reference's vectorised check also counts it as TP
+                     [0.5, 0.5, 0.9, 0.9],       # right box, wrong class -> FP
+                     [0.0, 0.6, 0.1, 0.7]], np.float32)   # no overlap -> FP
+    pr_c = np.array([0, 0, 1, 2])
+    c = ev.evaluate(pr_b, pr_c, gt_b, gt_c)
+    assert c["tp"].tolist() == [2, 0, 0] and c["fp"].tolist() == [0, 1, 1]
+    assert c["fn"].tolist() == [0, 0, 1] and c["gts"].tolist() == [1, 0, 1] and c["preds"].tolist() == [2, 1, 1]
+    assert c["examples"] == 1
+    ev.evaluate(pr_b, pr_c, gt_b, np.array([0, -1]))
+    assert ev.counters["errors"] == 1 and ev.counters["examples"] == 1
+    r, p_ = ev.recall_precision()
+    assert abs(r - 2 / 3) < 1e-9 and abs(p_ - 0.5) < 1e-9
+    b, cl, s_ = EvaluateDetections.gather_nms_output(pr_b, pr_c, np.arange(4.0), np.array([3, 1, 0, 0]), 2)
+    assert cl.tolist() == [2, 0] and s_.tolist() == [3.0, 1.0]

@@ -164,6 +164,19 @@ def main():
     with open(f"{a.data}/coco.names", "w") as f:
         for n in COCO_NAMES:
             f.write(n.replace("_", " ") + "\n")
+    # a synthetic RGBA sample image (the reference's girl.png is its own data file and is not copied): same kind of
+    # input -- non-square, with alpha -- for the single-image plumbing config
+    from PIL import Image, ImageDraw
+    os.makedirs(f"{a.data}/images", exist_ok=True)
+    rng = np.random.default_rng(2022)
+    base = (rng.random((333, 406, 4)) * 60 + 90).astype(np.uint8)
+    base[..., 3] = 255
+    im = Image.fromarray(base, "RGBA")
+    d = ImageDraw.Draw(im)
+    d.ellipse([60, 40, 220, 300], fill=(200, 120, 90, 255))
+    d.rectangle([250, 150, 380, 310], fill=(40, 90, 200, 255))
+    d.polygon([(20, 320), (120, 200), (200, 330)], fill=(60, 180, 80, 255))
+    im.save(f"{a.data}/images/sample.png")
 
 
 if __name__ == "__main__":

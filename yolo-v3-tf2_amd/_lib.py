@@ -70,6 +70,7 @@ SYMBOLS = {
     "y3_net_read_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_sz), _vp]),
     "y3_net_flops_per_image": (C.c_double, [_vp]),
     "y3_net_profile_convs": (_i, [_vp, _vp, _i, _fp, _i, _vp]),
+    "y3_preprocess_image": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "y3_yolo_decode": (_i, [C.POINTER(_vp), C.POINTER(C.c_int32), _i, _i, _fp, _vp, _vp, _vp, _vp]),
     "y3_yolo_decode_scores": (_i, [C.POINTER(_vp), C.POINTER(C.c_int32), _i, _i, _fp, _vp, _vp, _vp, _vp]),
     "y3_class_scores": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -26,7 +26,7 @@ def dir_filelist(images_dir, ext_list=".*"):
 
 def resize_bilinear(img, out_h, out_w):
     """tf.image.resize(img, (out_h, out_w)) default method (bilinear, antialias=False, half-pixel centres) for one
-    HWC float32 image -- reference call site: inference.py:158.  Rows then columns, fp32."""
+    HWC float32 image -- reference call site: inference.py:158.  fp32; host counterpart of y3_preprocess_image."""
     img = np.asarray(img, np.float32)
     in_h, in_w = img.shape[0], img.shape[1]
 
@@ -38,10 +38,12 @@ def resize_bilinear(img, out_h, out_w):
         hi = np.minimum(np.ceil(src), n_in - 1).astype(np.int64)
         return lo, hi, (src - fl).astype(np.float32)
 
-    lo, hi, fr = taps(in_h, out_h)
-    rows = img[lo] + (img[hi] - img[lo]) * fr[:, None, None]
-    lo, hi, fr = taps(in_w, out_w)
-    return (rows[:, lo] + (rows[:, hi] - rows[:, lo]) * fr[None, :, None]).astype(np.float32)
+    ylo, yhi, yfr = taps(in_h, out_h)
+    xlo, xhi, xfr = taps(in_w, out_w)
+    # TF's ResizeBilinear interpolates along x first (top and bottom rows), then along y
+    top = img[ylo][:, xlo] + (img[ylo][:, xhi] - img[ylo][:, xlo]) * xfr[None, :, None]
+    bot = img[yhi][:, xlo] + (img[yhi][:, xhi] - img[yhi][:, xlo]) * xfr[None, :, None]
+    return (top + (bot - top) * yfr[:, None, None]).astype(np.float32)
 
 
 def load_image_rgb01(path):
@@ -51,4 +53,12 @@ def load_image_rgb01(path):
     with Image.open(path) as im:
         im = im.convert("RGBA") if im.mode in ("RGBA", "LA", "P") else im.convert("RGB")
         a = np.asarray(im, np.uint8)[..., :3]
-    return a.astype(np.float32) / np.float32(255.0)
+    return a.astype(np.float32) * np.float32(1.0 / 255.0)   # convert_image_dtype: cast * (1 / 255)
+
+
+def load_image_u8(path):
+    """RGB uint8 [H,W,3] (alpha dropped) for the GPU input stage (runtime.preprocess_image)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        im = im.convert("RGBA") if im.mode in ("RGBA", "LA", "P") else im.convert("RGB")
+        return np.ascontiguousarray(np.asarray(im, np.uint8)[..., :3])

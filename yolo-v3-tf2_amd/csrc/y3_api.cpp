@@ -618,6 +618,19 @@ y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size
     return Y3_OK;
 }
 
+// ------------------------------------------------------------------------------------------ image input
+y3_status y3_preprocess_image(const void *image_dev, int is_uint8, int height, int width, int channels,
+                              float *batch_dev, int slot, int image_size, void *stream)
+{
+    if (!image_dev || !batch_dev || height <= 0 || width <= 0 || channels < 3 || channels > 4 || slot < 0 ||
+        image_size <= 0)
+        return fail(Y3_ERR_INVALID, "y3_preprocess_image: bad argument (channels must be 3 or 4)");
+    float *dst = batch_dev + (size_t)slot * image_size * image_size * 3;
+    hipError_t e = y3::launch_resize(image_dev, is_uint8, height, width, channels, dst, image_size, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_preprocess_image launch: %s", hipGetErrorString(e));
+    return Y3_OK;
+}
+
 // ------------------------------------------------------------------------------------------ decode
 static y3_status decode_common(const float *const grids[3], const int32_t gs[3], int batch, int nc,
                                const float *anchors, float *bboxes, float *conf, float *probs, int64_t *cls,

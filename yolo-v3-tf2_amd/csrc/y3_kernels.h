@@ -60,6 +60,8 @@ hipError_t launch_decode(const DecodeArgs &a, float *bboxes, float *conf, float 
 hipError_t launch_class_scores(const float *conf, const float *probs, size_t n, int nc, int64_t *cls,
                                float *scores, hipStream_t s);
 
+hipError_t launch_resize(const void *src, int is_u8, int H, int W, int pix_stride, float *dst, int S, hipStream_t s);
+
 size_t nms_workspace_bytes(int B, int N);
 hipError_t launch_nms(const float *boxes, const float *scores, int B, int N, int M, float T, float S, int32_t *sel,
                       int32_t *num_valid, void *ws, hipStream_t s);

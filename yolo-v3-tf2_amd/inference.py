@@ -14,7 +14,7 @@ import numpy as np
 import yaml
 
 from .core.parse_model import Input, ParseModel
-from .core.utils import dir_filelist, get_anchors, load_image_rgb01, resize_bilinear
+from .core.utils import dir_filelist, get_anchors, load_image_u8
 
 
 class DetectModel:
@@ -113,11 +113,16 @@ class Inference:
         else:
             filenames = []
         results = []
+        import torch
+        from . import runtime
         for image_index, file in enumerate(filenames):
-            orig_image = load_image_rgb01(file)                                   # reference: inference.py:157
-            image = resize_bilinear(orig_image, image_size, image_size)           # reference: inference.py:158
-            batch = image[None]
-            b_boxes, b_cls, b_scores, b_sel, b_nv = model.predict(batch)
+            # decode on the host, then uint8 -> [0,1] -> bilinear resize on the GPU straight into the batch tensor
+            # (reference: inference.py:157-158 decode_image + tf.image.resize)
+            orig_image = load_image_u8(file)
+            batch_dev = torch.empty((1, image_size, image_size, 3), dtype=torch.float32, device="cuda")
+            runtime.preprocess_image(torch.from_numpy(orig_image).cuda(), batch_dev, 0)
+            b_boxes, b_cls, b_scores, b_sel, b_nv = (t.cpu().numpy() for t in model(batch_dev))
+            batch = batch_dev.cpu().numpy()
             for bb, cc, ss, sel, nv, img in zip(b_boxes, b_cls, b_scores, b_sel, b_nv, batch):
                 bboxes, classes, scores = self.gather_valid_detections_results(bb, cc, ss, sel, int(nv))
                 classes_names = [class_names[idx] for idx in classes]

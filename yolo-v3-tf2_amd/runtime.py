@@ -249,6 +249,20 @@ def class_scores(conf, probs):
     return cls, scores
 
 
+def preprocess_image(image: torch.Tensor, batch: torch.Tensor, slot: int):
+    """image [H,W,3|4] uint8 or float32 on the GPU -> batch[slot] ([S,S,3] fp32, values in [0,1] for uint8 input):
+    decode_image's uint8->float conversion fused with tf.image.resize's bilinear resampling."""
+    _need_cuda(image, batch)
+    if image.dim() != 3 or image.dtype not in (torch.uint8, torch.float32) or batch.dtype != torch.float32:
+        raise Y3Error("image must be [H,W,C] uint8/float32 and batch float32 [B,S,S,3]")
+    if batch.dim() != 4 or batch.shape[1] != batch.shape[2] or batch.shape[3] != 3 or not (0 <= slot < batch.shape[0]):
+        raise Y3Error("batch must be [B,S,S,3] and slot inside it")
+    H, W, C_ = image.shape
+    check(_lib.load().y3_preprocess_image(_dev(image), int(image.dtype == torch.uint8), H, W, C_, _dev(batch), slot,
+                                          batch.shape[1], _lib.stream_ptr()), "y3_preprocess_image")
+    return batch
+
+
 _ws_cache: Dict[tuple, torch.Tensor] = {}
 
 
