@@ -288,19 +288,24 @@ def build_program(sub_models_configs: Sequence[dict], output_stage: str = "head"
     return prog
 
 
+def find_config_root(model_config_file: str, sub_models_configs) -> Optional[str]:
+    """Paths inside model.yaml are relative to the directory the reference is run from; when the process runs
+    elsewhere, walk up from the model file until they resolve."""
+    probe = sub_models_configs[0]["layers_config_file"]
+    if os.path.isabs(probe) or os.path.exists(probe):
+        return None
+    d = os.path.dirname(os.path.abspath(model_config_file))
+    while d != os.path.dirname(d):
+        if os.path.exists(os.path.join(d, probe)):
+            return d
+        d = os.path.dirname(d)
+    return None
+
+
 def load_program(model_config_file: str, nclasses: int = 80) -> Program:
     with open(model_config_file, "r") as f:
         cfg = yaml.safe_load(f)
-    root = None
-    probe = cfg["sub_models_configs"][0]["layers_config_file"]
-    if not os.path.exists(probe):
-        # paths in model.yaml are relative to the directory the reference is run from
-        d = os.path.dirname(os.path.abspath(model_config_file))
-        while d != os.path.dirname(d):
-            if os.path.exists(os.path.join(d, probe)):
-                root = d
-                break
-            d = os.path.dirname(d)
+    root = find_config_root(model_config_file, cfg["sub_models_configs"])
     return build_program(cfg["sub_models_configs"], cfg.get("output_stage", "head"), nclasses, root)
 
 

@@ -79,8 +79,11 @@ class Inference:
         nclasses = len(class_names)
         with open(model_config_file, "r") as f:
             model_config = yaml.safe_load(f)
+        from .graph import find_config_root
         model = ParseModel().build_model(Input(shape=(None, None, 3)), model_config["sub_models_configs"],
-                                         model_config["output_stage"], nclasses=nclasses)
+                                         model_config["output_stage"], nclasses=nclasses,
+                                         config_root=find_config_root(model_config_file,
+                                                                      model_config["sub_models_configs"]))
         with open("model_inference_summary.txt", "w") as f:
             model.summary(print_fn=lambda x: f.write(x + "\n"))
         if weights is not None:
