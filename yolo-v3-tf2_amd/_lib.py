@@ -23,12 +23,15 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
          (256, 128, 16, 1), (128, 64, 8, 1), (256, 64, 8, 1), (128, 64, 8, 2),
          (64, 128, 4, 1), (64, 128, 4, 1), (64, 128, 4, 1),  # 20..22: timing-only probes (wrong results)
          (128, 128, 4, 1), (128, 128, 4, 1),                # 23/24: 128x128 within 3 / 4 waves per SIMD of registers
-         (64, 128, 4, 1)]                                   # 25: probe 4 (timing only)
+         (64, 128, 4, 1),                                   # 25: probe 4 (timing only)
+         (64, 128, 4, 2), (64, 64, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (256, 32, 4, 2),  # 26..30: LDS-DMA operand loads
+         (64, 128, 4, 1), (64, 64, 4, 1)]                   # 31, 32: LDS-DMA, single LDS stage
 N_REAL_TILES = 20
 # bf16 kernel tiles: (BM, BN, waves, BK)
 TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
               (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64)]
-TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" for bm, bn, w, st in TILES]
+TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if i >= 26 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
+PROBE_TILES = (20, 21, 22, 25)  # timing-only ablations, wrong results
 
 
 class Y3Error(RuntimeError):

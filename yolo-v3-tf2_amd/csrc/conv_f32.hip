@@ -27,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int BK = 32;
-static constexpr int LDS_ROW = BK + 4;  // floats
+static constexpr int LDS_ROW_PADDED = BK + 4;  // floats (register-staged variant)
 
 // 16-byte buffer load: per-lane voffset (range-checked against num_records) + wave-uniform soffset
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff)
@@ -39,9 +39,14 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 // PROBE != 0 builds timing-only ablations of the main loop (wrong results; tools/tune_tiles.py --probe):
 //   1: LDS fragment reads + MFMA only   2: 1 + the two barriers   3: 2 + global fetches (never staged)
 //   4: MFMA + barriers only (fragments read from LDS once, before the loop)
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1>
+// DMA != 0: operand tiles are filled by direct-to-LDS buffer loads (no VGPR round trip, no ds_write): measured with
+// tools/mfma_probe.hip, a 16-B load to VGPRs costs the SIMD ~8-16 cycles of matrix-pipe time and a ds_write_b128 ~13,
+// an LDS-DMA load ~4.  LDS rows are then unpadded 128 B (a wave instruction writes 8 whole rows) and bank conflicts
+// are avoided by an XOR swizzle of the 16-B chunk index applied on the SOURCE address and on the fragment reads.
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvArgs p)
 {
+    constexpr int LDS_ROW = DMA ? BK : BK + 4;  // floats per LDS row
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
     constexpr int NT = 64 * WR * WC;
@@ -79,7 +84,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 
     // ---- per-thread gather state -------------------------------------------------------------
     const int lrow = tid >> 3;         // row inside a pass
-    const int lchunk = (tid & 7) * 4;  // first float of this lane's 16-B piece inside the 32-float K tile
+    // first float of this lane's 16-B piece inside the 32-float K tile (DMA: the piece that lands in physical chunk
+    // tid & 7 of the row is logical chunk (tid & 7) ^ ((row >> 1) & 7); rows of a pass differ by multiples of 32)
+    const int lchunk = DMA ? (((tid & 7) ^ ((lrow >> 1) & 7)) * 4) : (tid & 7) * 4;
     int aoff[AP];                      // element offset of (b, hi0, wi0, 0) in src0 (may be negative)
     int aoff1[CONCAT ? AP : 1];        // CONCAT: element offset of (b, ho, wo, 0) in src1
     int ahw[AP];                       // hi0 << 16 | (wi0 & 0xffff); row >= M marked by hi0 = -32768
@@ -149,6 +156,31 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 
     f32x4 ra[AP], rb[BP];
     int kglob = 0;  // k index of the next tile to fetch
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto fetch_dma = [&](int buf) {
+        // wave w fills rows [pass*RP + 8w, +8) of each tile: LDS destination = M0 base + lane*16
+        float *sa = smem + buf * STAGE + wave * 8 * LDS_ROW;
+        float *sb = sa + BM * LDS_ROW;
+        if (CONCAT && c0 >= p.C0) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sa + i * RP * LDS_ROW), 16, (int)avoff1[i], (c0 - p.C0) * 4, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < AP; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(sa + i * RP * LDS_ROW), 16, (int)avoff[i], c0 * 4, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * RP * LDS_ROW), 16, (int)boff[j], kglob * 4, 0, 0);
+        kglob += BK;
+        c0 += BK;
+        if (c0 == p.Cin) {
+            c0 = 0;
+            ++tap;
+            if (!CONCAT) set_tap();
+        }
+    };
     auto fetch = [&]() {
         if (CONCAT) {
             // channels [0,C0) come from src0, [C0,Cin) from src1; a 32-wide K tile never straddles (C0 % 32 == 0)
@@ -191,13 +223,21 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int KT = p.K / BK;
-    fetch();
-    stage(0);
+    if (DMA) {
+        fetch_dma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        fetch();
+        stage(0);
+    }
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
-    const int a_frag = (wr * 32 * TM + fr) * LDS_ROW + fh * 4;
-    const int b_frag = BM * LDS_ROW + (wc * 32 * TN + fr) * LDS_ROW + fh * 4;
+    const int a_frag = (wr * 32 * TM + fr) * LDS_ROW + (DMA ? 0 : fh * 4);
+    const int b_frag = BM * LDS_ROW + (wc * 32 * TN + fr) * LDS_ROW + (DMA ? 0 : fh * 4);
+    int foff[4];  // float offset of this lane's k-chunk q inside its row
+#pragma unroll
+    for (int q = 0; q < 4; ++q) foff[q] = DMA ? ((((2 * q + fh) ^ ((fr >> 1) & 7)) * 4)) : q * 8;
 
     f32x4 pfa[TM], pfb[TN];
     if (PROBE == 4) {
@@ -208,7 +248,10 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     }
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = (STAGES == 2) ? (kt & 1) : 0;
-        if (PROBE == 0 || PROBE == 3) {
+        if (DMA && STAGES == 2) {
+            if (kt + 1 < KT) fetch_dma(cur ^ 1);   // every wave passed the barrier that ended tile kt-1: buf cur^1 is free
+        } else if (DMA) {
+        } else if (PROBE == 0 || PROBE == 3) {
             if (kt + 1 < KT) fetch();
         }
         const float *sa = smem + cur * STAGE + a_frag;
@@ -223,9 +266,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                 for (int j = 0; j < TN; ++j) fb[j] = pfb[j];
             } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(sa + i * 32 * LDS_ROW + q * 8);
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(sa + i * 32 * LDS_ROW + foff[q]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(sb + j * 32 * LDS_ROW + q * 8);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(sb + j * 32 * LDS_ROW + foff[q]);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -235,7 +278,17 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
         }
-        if (PROBE != 0) {
+        if (DMA && STAGES == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 has landed (issued a whole K tile ago)
+            __syncthreads();
+        } else if (DMA) {
+            if (kt + 1 < KT) {
+                __syncthreads();   // every wave is done reading the single buffer
+                fetch_dma(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        } else if (PROBE != 0) {
             if (PROBE >= 2) {
                 __syncthreads();
                 __syncthreads();
@@ -272,7 +325,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wc * TN + j) * 32 + fr;
-            const float sc = p.scale[n], sh = p.shift[n];
+            const float sh = p.shift[n];   // the BN scale is folded into the packed weights (y3_api.cpp)
             const bool n_ok = n < p.Cout;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -297,7 +350,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    float v = acc[i][j][e] * sc + sh;
+                    float v = acc[i][j][e] + sh;
                     if (LEAKY) v = fmaxf(v, 0.1f * v);   // == (v >= 0 ? v : 0.1 v) for every finite v
                     if (RES) v = r[e] + v;
                     const int so = ((e & 3) + 8 * (e >> 2)) * row_bytes;
@@ -327,17 +380,19 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {64, 128, 4, 1}, {64, 128, 4, 1}, {64, 128, 4, 1},  // timing-only probes of tile 10 (wrong results)
     {128, 128, 4, 1}, {128, 128, 4, 1},                  // 128x128 with the register budget of 3 / 4 waves per SIMD
     {64, 128, 4, 1},                                     // probe 4
+    {64, 128, 4, 2}, {64, 64, 4, 2}, {128, 128, 4, 2}, {128, 64, 4, 2}, {256, 32, 4, 2},  // 26..30: LDS-DMA loads
+    {64, 128, 4, 1}, {64, 64, 4, 1},                     // 31, 32: LDS-DMA, single stage
 };
 
 TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUNT) ? tile : 0]; }
 
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1>
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0>
 static hipError_t launch_k(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
-    const size_t lds = STAGES * (size_t)(BM + BN) * LDS_ROW * sizeof(float);
-    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE, MINW>;
+    const size_t lds = STAGES * (size_t)(BM + BN) * (DMA ? BK : LDS_ROW_PADDED) * sizeof(float);
+    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE, MINW, DMA>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -349,11 +404,13 @@ static hipError_t launch_k(const ConvArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int TM, int TN, int WR, int WC>
+template <int TM, int TN, int WR, int WC, int MINW1 = 1>
 static hipError_t launch_t(const ConvArgs &a, int stages, hipStream_t s)
 {
-    if (a.src1) return stages == 2 ? launch_k<TM, TN, WR, WC, true, 2>(a, s) : launch_k<TM, TN, WR, WC, true, 1>(a, s);
-    return stages == 2 ? launch_k<TM, TN, WR, WC, false, 2>(a, s) : launch_k<TM, TN, WR, WC, false, 1>(a, s);
+    // MINW1: register budget (waves per SIMD) of the single-stage variant -- with 4, the two accumulators of the
+    // 32x64 wave tile stay in architectural VGPRs and the epilogue needs no v_accvgpr_read
+    if (a.src1) return stages == 2 ? launch_k<TM, TN, WR, WC, true, 2>(a, s) : launch_k<TM, TN, WR, WC, true, 1, 0, MINW1>(a, s);
+    return stages == 2 ? launch_k<TM, TN, WR, WC, false, 2>(a, s) : launch_k<TM, TN, WR, WC, false, 1, 0, MINW1>(a, s);
 }
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
@@ -364,8 +421,8 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 0: case 6: return launch_t<2, 2, 2, 2>(a, stages, s);    // 128x128, 4 waves
         case 1: case 7: return launch_t<2, 2, 4, 1>(a, stages, s);    // 256x64
         case 2: case 8: return launch_t<2, 1, 4, 1>(a, stages, s);    // 256x32
-        case 3: case 9: return launch_t<1, 2, 4, 1>(a, stages, s);    // 128x64
-        case 4: case 10: return launch_t<1, 2, 2, 2>(a, stages, s);   // 64x128
+        case 3: case 9: return launch_t<1, 2, 4, 1, 4>(a, stages, s);    // 128x64
+        case 4: case 10: return launch_t<1, 2, 2, 2, 4>(a, stages, s);   // 64x128
         case 5: case 11: return launch_t<1, 1, 2, 2>(a, stages, s);   // 64x64
         case 12: case 13: return launch_t<2, 1, 2, 4>(a, stages, s);  // 128x128, 8 waves
         case 14: case 15: return launch_t<1, 1, 4, 4>(a, stages, s);  // 128x128, 16 waves
@@ -376,6 +433,14 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 21: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 2>(a, s);
         case 22: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 3>(a, s);
         case 25: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 4>(a, s);
+        // direct-to-LDS operand loads, double buffered
+        case 26: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 0, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 0, 1, 1>(a, s);  // 64x128
+        case 27: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 0, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 0, 1, 1>(a, s);  // 64x64
+        case 28: return a.src1 ? launch_k<2, 2, 2, 2, true, 2, 0, 1, 1>(a, s) : launch_k<2, 2, 2, 2, false, 2, 0, 1, 1>(a, s);  // 128x128
+        case 29: return a.src1 ? launch_k<1, 2, 4, 1, true, 2, 0, 1, 1>(a, s) : launch_k<1, 2, 4, 1, false, 2, 0, 1, 1>(a, s);  // 128x64
+        case 30: return a.src1 ? launch_k<2, 1, 4, 1, true, 2, 0, 1, 1>(a, s) : launch_k<2, 1, 4, 1, false, 2, 0, 1, 1>(a, s);  // 256x32
+        case 31: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 1, 1>(a, s);  // 64x128, 1 stage
+        case 32: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 1>(a, s);  // 64x64, 1 stage
         case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 3>(a, s);
         case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 4>(a, s);
         default: return hipErrorInvalidValue;

@@ -277,11 +277,19 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
         for (int k = 0; k < K; ++k)
             for (int n = 0; n < d.cout; ++n) pk[(size_t)n * K + k] = w[(size_t)k * d.cout + n];
     }
+    // fp32 path: the BN scale is folded into the packed weights (one VALU multiply less per output element; VALU
+    // time is matrix-pipe time for the fp32 MFMA).  The bf16 copy keeps the unscaled weights + scale in the epilogue.
+    std::vector<float> pk_scaled;
+    if (!c.first_layer) {
+        pk_scaled = pk;
+        for (int n = 0; n < d.cout; ++n)
+            for (int k = 0; k < K; ++k) pk_scaled[(size_t)n * K + k] *= scale[n];
+    }
     HIP_TRY(hipSetDevice(net->device));
     if (!c.w_dev) HIP_TRY(hipMalloc(&c.w_dev, pk.size() * sizeof(float)));
     if (!c.scale_dev) HIP_TRY(hipMalloc(&c.scale_dev, CP * sizeof(float)));
     if (!c.shift_dev) HIP_TRY(hipMalloc(&c.shift_dev, CP * sizeof(float)));
-    HIP_TRY(hipMemcpy(c.w_dev, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.w_dev, (c.first_layer ? pk : pk_scaled).data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!c.first_layer) {
         std::vector<unsigned short> pb(pk.size());
         for (size_t i = 0; i < pk.size(); ++i) pb[i] = f32_to_bf16_rne(pk[i]);

@@ -29,7 +29,7 @@ struct ConvArgs {
 };
 
 // tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
-static constexpr int TILE_COUNT = 26;  // 20..22 are timing-only probes
+static constexpr int TILE_COUNT = 33;  // 20..22 are timing-only probes
 struct TileInfo { int bm, bn, waves, stages; };
 TileInfo conv_tile_info(int tile);
 
