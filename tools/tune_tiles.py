@@ -39,7 +39,7 @@ def main():
     net.plan(B, S, _lib.Y3_DTYPE_BF16 if bf else _lib.Y3_DTYPE_F32)
     x = torch.rand((B, S, S, 3), device="cuda")
     TL = _lib.TILES_BF16 if bf else TILES
-    TN_ = [f"{bm}x{bn}w{w}k{k}" for bm, bn, w, k in TL] if bf else TILE_NAMES
+    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if i >= 8 else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
     tiles = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else list(range(len(TL)))
     res = {}
     for t in [-1] + tiles:

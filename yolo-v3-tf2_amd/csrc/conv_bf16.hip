@@ -31,9 +31,12 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
     return (unsigned)a | ((unsigned)b << 16);
 }
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32>
+// DMA: operand tiles filled by direct-to-LDS buffer loads (BK = 64 only): unpadded 128-B rows, 16-B chunk index
+// XOR-swizzled with (row >> 1) & 7 on the source address and on the fragment reads (see conv_f32.hip).
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false>
 __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
 {
+    static_assert(!DMA || BK == 64, "LDS-DMA variant needs 128-byte rows");
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
     constexpr int NT = 64 * WR * WC;
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
     constexpr int RP = NT / LPR;     // rows per load pass
     constexpr int AP = BM / RP, BP = BN / RP;
     static_assert(BM % RP == 0 && BN % RP == 0 && AP >= 1 && BP >= 1, "tile too small for the thread count");
-    constexpr int ROWB = 2 * BK + 16;              // LDS row bytes
+    constexpr int ROWB = DMA ? 2 * BK : 2 * BK + 16;  // LDS row bytes
     constexpr int STAGE_B = (BM + BN) * ROWB;      // bytes per stage
     constexpr int CROW = BN + 4;                   // floats per row of the epilogue tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -67,7 +70,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
     const unsigned OOB0 = p.src0_bytes, OOB1 = CONCAT ? p.src1_bytes : p.src0_bytes;
 
     const int lrow = tid / LPR;
-    const int lchunk = (tid % LPR) * 8;  // first bf16 of this lane's 16-B piece inside the K tile
+    // first bf16 of this lane's 16-B piece inside the K tile (DMA: physical chunk tid & 7 holds logical chunk
+    // (tid & 7) ^ ((row >> 1) & 7))
+    const int lchunk = DMA ? (((tid % LPR) ^ ((lrow >> 1) & 7)) * 8) : (tid % LPR) * 8;
     int aoff[AP];
     int aoff1[CONCAT ? AP : 1];
     int ahw[AP];
@@ -129,6 +134,30 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
 
     u32x4 ra[AP], rb[BP];
     int kglob = 0;
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto fetch_dma = [&](int buf) {
+        unsigned char *sa = smem + buf * STAGE_B + wave * 8 * ROWB;   // wave w fills rows [pass*RP + 8w, +8)
+        unsigned char *sb = sa + BM * ROWB;
+        if (CONCAT && c0 >= p.C0) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sa + i * RP * ROWB), 16, (int)avoff1[i], (c0 - p.C0) * 2, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < AP; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(sa + i * RP * ROWB), 16, (int)avoff[i], c0 * 2, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * RP * ROWB), 16, (int)boff[j], kglob * 2, 0, 0);
+        kglob += BK;
+        c0 += BK;
+        if (c0 == p.Cin) {
+            c0 = 0;
+            ++tap;
+            if (!CONCAT) set_tap();
+        }
+    };
     auto fetch = [&]() {
         if (CONCAT) {
             if (c0 < p.C0) {
@@ -170,38 +199,68 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int KT = p.K / BK;
-    fetch();
-    stage(0);
+    if (DMA) {
+        fetch_dma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        fetch();
+        stage(0);
+    }
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
-    const int a_frag = (wr * 32 * TM + fr) * ROWB + fh * 16;
-    const int b_frag = BM * ROWB + (wc * 32 * TN + fr) * ROWB + fh * 16;
+    const int a_frag = (wr * 32 * TM + fr) * ROWB + (DMA ? 0 : fh * 16);
+    const int b_frag = BM * ROWB + (wc * 32 * TN + fr) * ROWB + (DMA ? 0 : fh * 16);
+    int foff[BK / 16];  // byte offset of this lane's 16-B piece of k-step s inside its row
+#pragma unroll
+    for (int s_ = 0; s_ < BK / 16; ++s_) foff[s_] = DMA ? (((2 * s_ + fh) ^ ((fr >> 1) & 7)) * 16) : s_ * 32;
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) fetch();
+        if (kt + 1 < KT) {
+            if (DMA) fetch_dma(cur ^ 1); else fetch();
+        }
         const unsigned char *sa = smem + cur * STAGE_B + a_frag;
         const unsigned char *sb = smem + cur * STAGE_B + b_frag;
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(sa + i * 32 * ROWB + s * 32);
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(sa + i * 32 * ROWB + foff[s]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(sb + j * 32 * ROWB + s * 32);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(sb + j * 32 * ROWB + foff[s]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) stage(cur ^ 1);
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (kt + 1 < KT) {
+            stage(cur ^ 1);
+        }
         __syncthreads();
     }
 
     // ---- epilogue through LDS ---------------------------------------------------------------------------
+    constexpr int PPR = BN / 8;                    // 16-byte pieces (8 bf16) per row
+    constexpr int NPC = (BM * PPR + NT - 1) / NT;  // pieces per thread
     float *C = reinterpret_cast<float *>(smem);
+    unsigned short *dstb = static_cast<unsigned short *>(p.dst);
+    const unsigned short *res = static_cast<const unsigned short *>(p.residual);
+    // the shortcut operand is fetched first so that its latency hides behind the accumulator write-out
+    u32x4 rr[OUT_F32 ? 1 : NPC];
+    if (!OUT_F32 && res) {
+#pragma unroll
+        for (int it = 0; it < NPC; ++it) {
+            const int pc = tid + it * NT;
+            const int row = pc / PPR, ch = (pc - row * PPR) * 8;
+            const int m = m0 + row;
+            rr[it] = (pc < BM * PPR && m < p.M) ? *reinterpret_cast<const u32x4 *>(res + (size_t)m * p.Cout + n0 + ch)
+                                                : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nl = (wc * TN + j) * 32 + fr;
@@ -226,29 +285,26 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
             if (m < p.M && n < p.Cout) dst[(size_t)m * p.Cout + n] = C[row * CROW + col];
         }
     } else {
-        constexpr int PPR = BN / 8;  // 16-byte pieces (8 bf16) per row
-        unsigned short *dst = static_cast<unsigned short *>(p.dst);
-        const unsigned short *res = static_cast<const unsigned short *>(p.residual);
-        for (int pc = tid; pc < BM * PPR; pc += NT) {
+#pragma unroll
+        for (int it = 0; it < NPC; ++it) {
+            const int pc = tid + it * NT;
             const int row = pc / PPR, ch = (pc - row * PPR) * 8;
             const int m = m0 + row;
-            if (m >= p.M) continue;
+            if (pc >= BM * PPR || m >= p.M) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4 *>(C + row * CROW + ch);
             const f32x4 v1 = *reinterpret_cast<const f32x4 *>(C + row * CROW + ch + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const size_t o = (size_t)m * p.Cout + n0 + ch;
             if (res) {
-                const u32x4 rr = *reinterpret_cast<const u32x4 *>(res + o);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    v[2 * k] = __uint_as_float(rr[k] << 16) + v[2 * k];
-                    v[2 * k + 1] = __uint_as_float(rr[k] & 0xffff0000u) + v[2 * k + 1];
+                    v[2 * k] = __uint_as_float(rr[it][k] << 16) + v[2 * k];
+                    v[2 * k + 1] = __uint_as_float(rr[it][k] & 0xffff0000u) + v[2 * k + 1];
                 }
             }
             u32x4 out;
 #pragma unroll
             for (int k = 0; k < 4; ++k) out[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
-            *reinterpret_cast<u32x4 *>(dst + o) = out;
+            *reinterpret_cast<u32x4 *>(dstb + (size_t)m * p.Cout + n0 + ch) = out;
         }
     }
 }
@@ -257,19 +313,20 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
 static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 32, 4, 64},
     {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 64},
+    {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {64, 128, 4, 64}, {128, 256, 8, 64},  // 8..13: LDS-DMA
 };
 
 TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < BF16_TILE_COUNT) ? tile : 0]; }
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32>
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false>
 static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
-    const size_t stages = 2 * (size_t)(BM + BN) * (2 * BK + 16);
+    const size_t stages = 2 * (size_t)(BM + BN) * (DMA ? 2 * BK : 2 * BK + 16);
     const size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
     const size_t lds = stages > ctile ? stages : ctile;
-    auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32>;
+    auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, DMA>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -281,12 +338,12 @@ static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int TM, int TN, int WR, int WC, int BK>
+template <int TM, int TN, int WR, int WC, int BK, bool DMA = false>
 static hipError_t launch_tb(const ConvArgs &a, bool out_f32, hipStream_t s)
 {
     if (a.src1)
-        return out_f32 ? launch_kb<TM, TN, WR, WC, BK, true, true>(a, s) : launch_kb<TM, TN, WR, WC, BK, true, false>(a, s);
-    return out_f32 ? launch_kb<TM, TN, WR, WC, BK, false, true>(a, s) : launch_kb<TM, TN, WR, WC, BK, false, false>(a, s);
+        return out_f32 ? launch_kb<TM, TN, WR, WC, BK, true, true, DMA>(a, s) : launch_kb<TM, TN, WR, WC, BK, true, false, DMA>(a, s);
+    return out_f32 ? launch_kb<TM, TN, WR, WC, BK, false, true, DMA>(a, s) : launch_kb<TM, TN, WR, WC, BK, false, false, DMA>(a, s);
 }
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
@@ -303,6 +360,12 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
         case 5: return launch_tb<2, 1, 2, 2, 32>(a, out_f32, s);
         case 6: return launch_tb<1, 1, 2, 2, 32>(a, out_f32, s);
         case 7: return launch_tb<1, 2, 2, 2, 64>(a, out_f32, s);
+        case 8: return launch_tb<2, 2, 2, 2, 64, true>(a, out_f32, s);    // 128x128 LDS-DMA
+        case 9: return launch_tb<2, 2, 4, 2, 64, true>(a, out_f32, s);    // 256x128, 8 waves, LDS-DMA
+        case 10: return launch_tb<2, 1, 2, 2, 64, true>(a, out_f32, s);   // 128x64 LDS-DMA
+        case 11: return launch_tb<1, 1, 2, 2, 64, true>(a, out_f32, s);   // 64x64 LDS-DMA
+        case 12: return launch_tb<1, 2, 2, 2, 64, true>(a, out_f32, s);   // 64x128 LDS-DMA
+        case 13: return launch_tb<2, 2, 2, 4, 64, true>(a, out_f32, s);   // 128x256, 8 waves, LDS-DMA
         default: return hipErrorInvalidValue;
     }
 }
@@ -345,7 +408,7 @@ __global__ __launch_bounds__(256) void conv_first_bf16(const ConvArgs p, const f
             for (int c = 0; c < 3; ++c) {
                 const float *wr = w + ((u * 3 + v) * 3 + c) * COUT;
 #pragma unroll
-                for (int n = 0; n < COUT; ++n) acc[n] += xv[c] * wr[n];
+                for (int n = 0; n < COUT; ++n) acc[n] = __builtin_fmaf(xv[c], wr[n], acc[n]);  // one VALU op per MAC (the file is built with -ffp-contract=off)
             }
         }
     }

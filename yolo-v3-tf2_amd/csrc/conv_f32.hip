@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void conv_first_f32(const ConvArgs p, const fl
             for (int c = 0; c < 3; ++c) {
                 const float *wr = w + ((u * 3 + v) * 3 + c) * COUT;  // HWIO, wave-uniform address -> scalar loads
 #pragma unroll
-                for (int n = 0; n < COUT; ++n) acc[n] += xv[c] * wr[n];
+                for (int n = 0; n < COUT; ++n) acc[n] = __builtin_fmaf(xv[c], wr[n], acc[n]);  // one VALU op per MAC (the file is built with -ffp-contract=off)
             }
         }
     }

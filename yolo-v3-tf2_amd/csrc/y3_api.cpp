@@ -109,9 +109,9 @@ int choose_tile_bf16(const ConvSlot &c, long long M)
     if (c.d.cin % 64)
         cand = {5, 6};                       // BK = 32 (Cin = 32 layers, Cout = 64)
     else if (c.cout_pad % 128 == 0)
-        cand = {0, 7, 3};
+        cand = {8, 12, 11};                  // LDS-DMA variants: 128x128, 64x128, 64x64
     else if (c.cout_pad % 64 == 0)
-        cand = {2, 3};
+        cand = {10, 11};
     else
         cand = {4};
     int best = cand.back();
