@@ -59,6 +59,12 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="also print the per-conv timing table to stderr")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner) write to fd 1 directly, so
+    # fd 1 points at stderr until the line is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -74,8 +80,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     require_gpu()
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or os.environ.get("Y3_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL with one rank
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     B, S, nc, M = args.batch, args.image_size, 80, 100
 
     program = load_program(os.path.join(ROOT, "config/models/yolov3/model.yaml"), nc)
@@ -91,7 +100,7 @@ def main():
     grids = [torch.empty((B, g, g, 3, 5 + nc), device="cuda") for g in net.grid_sizes()]
     from yolo_v3_tf2_amd.parallel import allgather_detections
     gathered = None
-    if world > 1:
+    if use_dist:
         gathered = (torch.empty((world * B, M, 7), dtype=torch.int32, device="cuda"),
                     torch.empty((world * B,), dtype=torch.int32, device="cuda"))
 
@@ -109,7 +118,7 @@ def main():
         return allgather_detections(packed, nv, out=gathered)   # RCCL all-gather when world > 1
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -136,7 +145,7 @@ def main():
             out = step(i)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -176,7 +185,7 @@ def main():
             "data": "synthetic (uniform [0,1) images, seeded random-init weights; no checkpoint ships with the reference)",
             "config": {"workload": f"full YOLOv3 detect, {B} images/GPU, {S}x{S}, 80 classes, {'fp32' if args.dtype == 'f32' else 'bf16'} MFMA conv, "
                                    f"decode + class-agnostic NMS (max 100, iou 0.5, score 0.1), packed detections"
-                                   + (", RCCL all-gather" if world > 1 else ""),
+                                   + (", RCCL all-gather" if use_dist else ""),
                        "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
                        "mean_num_valid": round(nv_mean, 2)},
             "roofline": {
@@ -196,8 +205,11 @@ def main():
                 fl = 2.0 * o.size * o.size * o.cin * o.cout * ho * ho * B
                 print(f"conv{o.conv_index:<3d} {o.size}x{o.size}/{o.stride} {o.cin:>4d}->{o.cout:<4d} @{ho:<3d} "
                       f"{t:8.3f} ms {fl / t / 1e9:8.1f} TF/s", file=sys.stderr)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if use_dist:
         dist.destroy_process_group()
 
 

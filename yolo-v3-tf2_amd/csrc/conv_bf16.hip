@@ -390,9 +390,10 @@ __global__ __launch_bounds__(256) void conv_first_bf16(const ConvArgs p, const f
     const int r = mm - b * HW;
     const int ho = r / p.W, wo = r - ho * p.W;
     const float *x = static_cast<const float *>(p.src0);
-    float acc[COUT];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[COUT / 2];   // packed pairs: v_pk_fma_f32 retires two MACs per VALU instruction
 #pragma unroll
-    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
+    for (int n = 0; n < COUT / 2; ++n) acc2[n] = f32x2{0.0f, 0.0f};
 #pragma unroll 1
     for (int u = 0; u < 3; ++u) {
         const int hi = ho - 1 + u;
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(256) void conv_first_bf16(const ConvArgs p, const f
             for (int c = 0; c < 3; ++c) {
                 const float *wr = w + ((u * 3 + v) * 3 + c) * COUT;
 #pragma unroll
-                for (int n = 0; n < COUT; ++n) acc[n] = __builtin_fmaf(xv[c], wr[n], acc[n]);  // one VALU op per MAC (the file is built with -ffp-contract=off)
+                for (int n = 0; n < COUT; n += 2)
+                    acc2[n / 2] = __builtin_elementwise_fma(f32x2{xv[c], xv[c]}, f32x2{wr[n], wr[n + 1]}, acc2[n / 2]);
             }
         }
     }
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void conv_first_bf16(const ConvArgs p, const f
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float v = acc[n + e] * p.scale[n + e] + p.shift[n + e];
+            float v = acc2[(n + e) / 2][(n + e) & 1] * p.scale[n + e] + p.shift[n + e];
             if (p.leaky) v = fmaxf(v, 0.1f * v);
             o[e] = v;
         }

@@ -30,8 +30,6 @@ def allgather_detections(packed: torch.Tensor, num_valid: torch.Tensor, group=No
     if not (dist.is_available() and dist.is_initialized()):
         return packed, num_valid
     world = dist.get_world_size(group)
-    if world == 1:
-        return packed, num_valid
     if out is None:
         out = (torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype,
                            device=packed.device),
