@@ -145,10 +145,7 @@ def forward(program, weights, images, acc64=False, keep=None, bf16=False):
         for i in n.inputs:
             last_use[i] = idx
     keep = set(keep or ())
-    outs_needed = set()
-    for n in program.nodes:
-        if n.kind == "yolo" and n.output in _yolo_outputs(program):
-            outs_needed.add(n.output)
+    outs_needed = set(_yolo_outputs(program)) | set(program.outputs)
     kept = {}
     for idx, n in enumerate(program.nodes):
         if n.kind == "conv":
