@@ -243,68 +243,71 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
         __syncthreads();
     }
 
-    // ---- epilogue through LDS ---------------------------------------------------------------------------
-    constexpr int PPR = BN / 8;                    // 16-byte pieces (8 bf16) per row
-    constexpr int NPC = (BM * PPR + NT - 1) / NT;  // pieces per thread
+    // ---- epilogue through LDS, one 32-row sub-tile of every wave per pass ----------------------------------
+    // pass i: wave (wr, wc) writes rows [wr*32, +32) x cols [wc*32*TN, +32*TN) of a [WR*32][BN+4] fp32 tile (its i-th
+    // accumulator row block), then all threads convert 8 consecutive channels each and store 16 B.
+    constexpr int EROWS = WR * 32;
+    constexpr int PPR = BN / 8;                       // 16-byte pieces (8 bf16) per row
+    constexpr int NPC = (EROWS * PPR + NT - 1) / NT;  // pieces per thread per pass
     float *C = reinterpret_cast<float *>(smem);
     unsigned short *dstb = static_cast<unsigned short *>(p.dst);
     const unsigned short *res = static_cast<const unsigned short *>(p.residual);
-    // the shortcut operand is fetched first so that its latency hides behind the accumulator write-out
-    u32x4 rr[OUT_F32 ? 1 : NPC];
-    if (!OUT_F32 && res) {
 #pragma unroll
-        for (int it = 0; it < NPC; ++it) {
-            const int pc = tid + it * NT;
-            const int row = pc / PPR, ch = (pc - row * PPR) * 8;
-            const int m = m0 + row;
-            rr[it] = (pc < BM * PPR && m < p.M) ? *reinterpret_cast<const u32x4 *>(res + (size_t)m * p.Cout + n0 + ch)
-                                                : u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < TM; ++i) {
+        // tile row of chunk row r: (r / 32) * 32 * TM + i * 32 + r % 32
+        u32x4 rr[OUT_F32 ? 1 : NPC];
+        if (!OUT_F32 && res) {   // shortcut operand first: its latency hides behind the accumulator write-out
+#pragma unroll
+            for (int it = 0; it < NPC; ++it) {
+                const int pc = tid + it * NT;
+                const int r = pc / PPR, ch = (pc - r * PPR) * 8;
+                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31);
+                rr[it] = (pc < EROWS * PPR && m < p.M) ? *reinterpret_cast<const u32x4 *>(res + (size_t)m * p.Cout + n0 + ch)
+                                                       : u32x4{0u, 0u, 0u, 0u};
+            }
         }
-    }
+        if (i > 0) __syncthreads();   // previous pass fully read
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nl = (wc * TN + j) * 32 + fr;
-        const float sc = p.scale[n0 + nl], sh = p.shift[n0 + nl];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int ml = (wr * TM + i) * 32 + 4 * fh;
+        for (int j = 0; j < TN; ++j) {
+            const int nl = (wc * TN + j) * 32 + fr;
+            const float sc = p.scale[n0 + nl], sh = p.shift[n0 + nl];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = acc[i][j][e] * sc + sh;
                 if (p.leaky) v = fmaxf(v, 0.1f * v);
-                C[(ml + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
+                C[(wr * 32 + 4 * fh + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
             }
         }
-    }
-    __syncthreads();
-    if (OUT_F32) {
-        float *dst = static_cast<float *>(p.dst);
-        for (int idx = tid; idx < BM * BN; idx += NT) {
-            const int row = idx / BN, col = idx - row * BN;
-            const int m = m0 + row, n = n0 + col;
-            if (m < p.M && n < p.Cout) dst[(size_t)m * p.Cout + n] = C[row * CROW + col];
-        }
-    } else {
+        __syncthreads();
+        if (OUT_F32) {
+            float *dst = static_cast<float *>(p.dst);
+            for (int idx = tid; idx < EROWS * BN; idx += NT) {
+                const int r = idx / BN, col = idx - r * BN;
+                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31), n = n0 + col;
+                if (m < p.M && n < p.Cout) dst[(size_t)m * p.Cout + n] = C[r * CROW + col];
+            }
+        } else {
 #pragma unroll
-        for (int it = 0; it < NPC; ++it) {
-            const int pc = tid + it * NT;
-            const int row = pc / PPR, ch = (pc - row * PPR) * 8;
-            const int m = m0 + row;
-            if (pc >= BM * PPR || m >= p.M) continue;
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(C + row * CROW + ch);
-            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(C + row * CROW + ch + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            if (res) {
+            for (int it = 0; it < NPC; ++it) {
+                const int pc = tid + it * NT;
+                const int r = pc / PPR, ch = (pc - r * PPR) * 8;
+                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31);
+                if (pc >= EROWS * PPR || m >= p.M) continue;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(C + r * CROW + ch);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(C + r * CROW + ch + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (res) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[2 * k] = __uint_as_float(rr[it][k] << 16) + v[2 * k];
-                    v[2 * k + 1] = __uint_as_float(rr[it][k] & 0xffff0000u) + v[2 * k + 1];
+                    for (int k = 0; k < 4; ++k) {
+                        v[2 * k] = __uint_as_float(rr[it][k] << 16) + v[2 * k];
+                        v[2 * k + 1] = __uint_as_float(rr[it][k] & 0xffff0000u) + v[2 * k + 1];
+                    }
                 }
-            }
-            u32x4 out;
+                u32x4 out;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) out[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
-            *reinterpret_cast<u32x4 *>(dstb + (size_t)m * p.Cout + n0 + ch) = out;
+                for (int k = 0; k < 4; ++k) out[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
+                *reinterpret_cast<u32x4 *>(dstb + (size_t)m * p.Cout + n0 + ch) = out;
+            }
         }
     }
 }
@@ -314,6 +317,7 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 32, 4, 64},
     {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 64},
     {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {64, 128, 4, 64}, {128, 256, 8, 64},  // 8..13: LDS-DMA
+    {256, 256, 8, 64}, {256, 128, 4, 64}, {128, 256, 4, 64},  // 14..16: LDS-DMA, 128x64 / 64x128 wave tiles
 };
 
 TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < BF16_TILE_COUNT) ? tile : 0]; }
@@ -324,7 +328,7 @@ static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
     const size_t stages = 2 * (size_t)(BM + BN) * (DMA ? 2 * BK : 2 * BK + 16);
-    const size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
+    const size_t ctile = (size_t)WR * 32 * (BN + 4) * sizeof(float);   // epilogue tile: one 32-row block per wave row
     const size_t lds = stages > ctile ? stages : ctile;
     auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, DMA>;
     static bool attr_set = false;
@@ -366,6 +370,9 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
         case 11: return launch_tb<1, 1, 2, 2, 64, true>(a, out_f32, s);   // 64x64 LDS-DMA
         case 12: return launch_tb<1, 2, 2, 2, 64, true>(a, out_f32, s);   // 64x128 LDS-DMA
         case 13: return launch_tb<2, 2, 2, 4, 64, true>(a, out_f32, s);   // 128x256, 8 waves, LDS-DMA
+        case 14: return launch_tb<4, 2, 2, 4, 64, true>(a, out_f32, s);   // 256x256, 8 waves (128x64 wave tile), LDS-DMA
+        case 15: return launch_tb<4, 2, 2, 2, 64, true>(a, out_f32, s);   // 256x128, 4 waves (128x64 wave tile), LDS-DMA
+        case 16: return launch_tb<2, 4, 2, 2, 64, true>(a, out_f32, s);   // 128x256, 4 waves (64x128 wave tile), LDS-DMA
         default: return hipErrorInvalidValue;
     }
 }
