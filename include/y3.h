@@ -38,7 +38,7 @@ enum {
 };
 
 /* activation storage / MFMA input type of the conv stack */
-enum { Y3_DTYPE_F32 = 0, Y3_DTYPE_BF16 = 1 };
+enum { Y3_DTYPE_F32 = 0, Y3_DTYPE_BF16 = 1, Y3_DTYPE_F32X3 = 2 };
 
 int y3_version(void);
 const char *y3_last_error(void);
@@ -108,6 +108,7 @@ y3_status y3_net_set_conv_weights(y3_net *net, int conv_slot, const float *w, co
  * intermediate after a forward. */
 y3_status y3_net_set_tile(y3_net *net, int conv_slot, int tile);
 y3_status y3_net_set_tile_bf16(y3_net *net, int conv_slot, int tile);
+y3_status y3_net_set_tile_x3(y3_net *net, int conv_slot, int tile);
 /* Run a forward as `lanes` (1..4) equal sub-batches on forked internal streams joined back into the caller's
  * stream: the tail of one sub-batch's conv kernel overlaps the next kernel of another.  Results are unchanged
  * (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
@@ -117,7 +118,10 @@ y3_status y3_net_keep_activations(y3_net *net, int keep);
 /* Allocate the activation arena for batches up to `max_batch` of image_size x image_size inputs
  * and select the conv arithmetic type (Y3_DTYPE_*).  May be called again to re-plan.
  * Y3_DTYPE_BF16: intermediate activations and weights are bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate and
- * epilogue); the image batch stays fp32 (the Cin = 3 first layer reads it directly) and the head grids stay fp32. */
+ * epilogue); the image batch stays fp32 (the Cin = 3 first layer reads it directly) and the head grids stay fp32.
+ * Y3_DTYPE_F32X3: fp32-accurate arithmetic on the bf16 matrix cores -- every value is held as three bf16 planes
+ * (x = hi + mid + lo exactly) and each product uses its six leading partial products with fp32 accumulation; same
+ * image / head-grid conventions, same parity bar as Y3_DTYPE_F32. */
 y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype);
 
 /* images_dev [B,S,S,3] fp32 -> grids_dev[3], each [B,g,g,3*(5+nc)] fp32 (== [B,g,g,3,5+nc]).

@@ -110,6 +110,85 @@ def test_upsample_concat_fused_conv(rt, program, weights):
         assert np.abs(g - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
 
 
+# ---------------------------------------------------------------------------------------------- f32x3
+# fp32-accurate arithmetic on the bf16 matrix cores (three bf16 planes per value): held to the fp32 path's tolerances
+# against the fp32 oracle.
+@pytest.mark.parametrize("case", range(len(CONV_CASES)))
+def test_x3_conv_layers_match_fp32_oracle(rt, case):
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    in_ch, S, B, chain, heads = CONV_CASES[case]
+    p = mini_program(in_ch, chain, heads)
+    w = synthetic_weights(p, seed=100 + case)
+    rng = np.random.default_rng(case)
+    x = (rng.standard_normal((B, S, S, in_ch)) if in_ch != 3 else rng.random((B, S, S, in_ch))).astype(np.float32)
+    ref = O.forward(p, w, x)
+    net = rt.Net(p)
+    net.load_weights(w)
+    net.plan(B, S, _lib.Y3_DTYPE_F32X3)
+    xin = _cuda(x) if in_ch == 3 else rt.split3_planes(_cuda(x))
+    got = net.forward(xin)
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        g = g.cpu().numpy().reshape(r.shape)
+        tol = 2e-5 * max(1.0, float(np.abs(r).max()))
+        assert np.abs(g - r).max() <= tol, (case, float(np.abs(g - r).max()), tol)
+
+
+@pytest.mark.parametrize("tile", range(9))
+def test_x3_every_tile(rt, tile):
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    bm, bn, _, bk = _lib.TILES_X3[tile]
+    p = mini_program(64, [], [dict(filters=bn, size=3), dict(filters=bn, size=1), dict(filters=bn, size=3, stride=2)])
+    w = synthetic_weights(p, seed=9)
+    x = np.random.default_rng(9).standard_normal((3, 14, 14, 64)).astype(np.float32)
+    ref = O.forward(p, w, x)
+    net = rt.Net(p)
+    net.load_weights(w)
+    for slot in range(3):
+        net.set_tile_x3(slot, tile)
+    net.plan(3, 14, _lib.Y3_DTYPE_F32X3)
+    got = net.forward(rt.split3_planes(_cuda(x)))
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        assert np.abs(g.cpu().numpy().reshape(r.shape) - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
+
+
+@pytest.mark.parametrize("S,B", [(96, 2), (160, 1)])
+def test_x3_network_and_detect_match_fp32_oracle(rt, program, weights, anchors, S, B):
+    """Full network + decode + NMS in the three-plane mode: head logits within 1e-4 of the fp32 oracle (the fp32 path's
+    bar), boxes/scores within 1e-4, NMS bit-exact on the device's own boxes/scores; fused upsample+concat convs and
+    residual tensors checked as fp32 reconstructions."""
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    x = np.random.default_rng(1234).random((B, S, S, 3), dtype=np.float32)
+    ops = program.conv_ops()
+    probe = [ops[3].dst, ops[25].dst] + [o.dst for o in ops if o.src1 >= 0]
+    ref, kept = O.forward(program, weights, x, keep=set(probe))
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.keep_activations(True)
+    net.plan(B, S, _lib.Y3_DTYPE_F32X3)
+    got = net.forward(_cuda(x))
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        assert np.abs(g.cpu().numpy() - r).max() <= 1e-4
+    for t in probe:
+        g = net.read_tensor(t, B).cpu().numpy()
+        assert np.abs(g - kept[t]).max() <= 2e-5 * max(1.0, float(np.abs(kept[t]).max()))
+    gb, gc, gs = rt.yolo_decode_scores(got, anchors, 80)
+    gsel, gnv = rt.nms_padded(gb, gs, 100, 0.5, 0.1)
+    rb, rc, rs, rsel, rnv = O.yolo_nms(O.yolo_decode(ref, anchors, 80), 100, 0.5, 0.1)
+    assert np.abs(gb.cpu().numpy() - rb).max() <= 1e-4 and np.abs(gs.cpu().numpy() - rs).max() <= 1e-4
+    s2, n2 = O.nms_padded(gb.cpu().numpy(), gs.cpu().numpy(), 100, 0.5, 0.1)
+    assert np.array_equal(s2, gsel.cpu().numpy()) and np.array_equal(n2, gnv.cpu().numpy())
+
+
 # ---------------------------------------------------------------------------------------------- bf16 (config 5)
 BF16_CASES = [
     (64, 16, 3, [], [dict(filters=128, size=3, stride=2), dict(filters=128, size=3), dict(filters=255, size=1, bn=False, act="linear")]),

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--tiles", type=str, default="all")
     ap.add_argument("--write", type=str, default="")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3"], default="f32")
     a = ap.parse_args()
     B, S = a.batch, a.image_size
     p = load_program(os.path.join(ROOT, "config/models/yolov3/model.yaml"), 80)
@@ -35,23 +35,24 @@ def main():
     net = runtime.Net(p)
     net.load_weights(w)
     from yolo_v3_tf2_amd import _lib
-    bf = a.dtype == "bf16"
-    net.plan(B, S, _lib.Y3_DTYPE_BF16 if bf else _lib.Y3_DTYPE_F32)
+    bf = a.dtype in ("bf16", "f32x3")   # tile tables with a BK column
+    x3 = a.dtype == "f32x3"
+    net.plan(B, S, {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3}[a.dtype])
     x = torch.rand((B, S, S, 3), device="cuda")
-    TL = _lib.TILES_BF16 if bf else TILES
-    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if i >= 8 else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
+    TL = _lib.TILES_X3 if x3 else _lib.TILES_BF16 if bf else TILES
+    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if (i >= 8 and not x3) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
     tiles = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else list(range(len(TL)))
     res = {}
     for t in [-1] + tiles:
         bn = TL[t][1] if t >= 0 else 0
         ok = []
         for slot, o in enumerate(net.conv_ops):
-            cp = (o.cout + 31) // 32 * 32
+            cp = (o.cout + 63) // 64 * 64 if x3 else (o.cout + 31) // 32 * 32
             legal = t < 0 or (o.cin != 3 and cp % bn == 0 and not (not bf and t in (20, 21, 22, 25) and o.src1 >= 0))
             if bf and t >= 0:
                 legal = legal and o.cin % TL[t][3] == 0 and (o.src1 < 0 or o.c0 % TL[t][3] == 0)
             ok.append(legal)
-            (net.set_tile_bf16 if bf else net.set_tile)(slot, t if legal else -1)
+            (net.set_tile_x3 if x3 else net.set_tile_bf16 if bf else net.set_tile)(slot, t if legal else -1)
         best = None
         for _ in range(a.reps):
             ms = net.profile_convs(x)

@@ -14,7 +14,7 @@ from . import PACKAGE_DIR
 LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "liby3hip.so")
 
 Y3_OK = 0
-Y3_DTYPE_F32, Y3_DTYPE_BF16 = 0, 1
+Y3_DTYPE_F32, Y3_DTYPE_BF16, Y3_DTYPE_F32X3 = 0, 1, 2
 Y3_AUX_ADD, Y3_AUX_UPSAMPLE2X, Y3_AUX_CONCAT = 0, 1, 2
 # (BM, BN, waves, LDS stages) of every tile id of the fp32 MFMA conv kernel (mirror of kTiles in csrc/conv_f32.hip)
 TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (64, 128, 4, 2), (64, 64, 4, 2),
@@ -27,6 +27,9 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
          (64, 128, 4, 2), (64, 64, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (256, 32, 4, 2),  # 26..30: LDS-DMA operand loads
          (64, 128, 4, 1), (64, 64, 4, 1)]                   # 31, 32: LDS-DMA, single LDS stage
 N_REAL_TILES = 20
+# three-plane (fp32-accurate on bf16 MFMA) kernel tiles: (BM, BN, waves, BK)
+TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), (256, 64, 4, 32),
+            (128, 64, 4, 64), (64, 64, 4, 64), (128, 256, 8, 32)]
 # bf16 kernel tiles: (BM, BN, waves, BK)
 TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
               (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64),
@@ -68,6 +71,7 @@ SYMBOLS = {
     "y3_net_set_conv_weights": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _f]),
     "y3_net_set_tile": (_i, [_vp, _i, _i]),
     "y3_net_set_tile_bf16": (_i, [_vp, _i, _i]),
+    "y3_net_set_tile_x3": (_i, [_vp, _i, _i]),
     "y3_net_keep_activations": (_i, [_vp, _i]),
     "y3_net_set_lanes": (_i, [_vp, _i]),
     "y3_net_plan": (_i, [_vp, _i, _i, _i]),

@@ -1,0 +1,476 @@
+// fp32-accurate convolution on the bf16 matrix cores: every fp32 value is carried as THREE bf16 planes
+// (hi, mid, lo: x = hi + mid + lo exactly, 3 x 8 significand bits = the 24 bits of fp32) and every product
+// a*b is formed from the six leading partial products
+//      hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid          (dropped terms are <= 2^-24 |a*b|)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  bf16 x bf16 products are exact in fp32, so the result has
+// fp32-level accuracy (the parity bar of the fp32 path -- 1e-4 on boxes/scores against the fp32 oracle -- is the
+// bar of this path, same tests) at 1/6 of the bf16 MFMA rate = 2.67x the rate of v_mfma_f32_32x32x2_f32.
+//
+// Same fused op as conv_f32.hip / conv_bf16.hip (reference: core/parse_model.py:27-52,72,134,155-156).
+// Layout: activations [pixel][plane 0..2][C] bf16, weights [CoutPad][plane][K] bf16, head outputs fp32.
+// Operand tiles go HBM/L2 -> LDS by direct-to-LDS buffer loads (one tile per plane), double buffered; LDS rows are
+// 2*BK bytes with the 16-B chunk index XOR-swizzled on the source address and on the fragment reads.
+#include <type_traits>
+
+#include "y3_kernels.h"
+
+namespace y3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+
+// x -> (hi, mid, lo) bf16 bit patterns with hi + mid + lo == x (fp32 subtractions of nearby values are exact)
+__device__ __forceinline__ void split3(float x, unsigned short &hi, unsigned short &mid, unsigned short &lo)
+{
+    const float h = bf16_round(x);
+    const float r1 = x - h;
+    const float m = bf16_round(r1);
+    const float r2 = r1 - m;
+    hi = bf16_bits(h);
+    mid = bf16_bits(m);
+    lo = bf16_bits(r2);
+}
+
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32>
+__global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p)
+{
+    constexpr int BM = 32 * TM * WR;
+    constexpr int BN = 32 * TN * WC;
+    constexpr int NT = 64 * WR * WC;
+    constexpr int LPR = BK / 8;        // 16-B chunks (8 bf16) per row: 4 or 8
+    constexpr int RPI = 64 / LPR;      // rows written by one wave-wide LDS-DMA instruction
+    constexpr int RP = NT / LPR;       // rows per load pass of the whole workgroup
+    constexpr int AP = BM / RP, BP = BN / RP;
+    static_assert(BM % RP == 0 && BN % RP == 0 && AP >= 1 && BP >= 1, "tile too small for the thread count");
+    constexpr int ROWB = 2 * BK;                      // LDS row bytes (64 or 128)
+    constexpr int PLANE_B = (BM + BN) * ROWB;         // one plane of one stage: A rows then B rows
+    constexpr int STAGE_B = 3 * PLANE_B;
+    constexpr int CROW = BN + 4;
+    constexpr int SWZ_SHIFT = (LPR == 8) ? 1 : 2;     // swizzle key: (row >> SWZ_SHIFT) & (LPR - 1)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tilesN = p.CoutPad / BN;
+    const int mt = logical / tilesN, nt = logical - mt * tilesN;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.src0), 0, p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(CONCAT ? p.src1 : p.src0), 0, CONCAT ? p.src1_bytes : p.src0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wpk), 0, p.w_bytes, 0x00020000);
+    const unsigned OOB0 = p.src0_bytes, OOB1 = CONCAT ? p.src1_bytes : p.src0_bytes;
+
+    const int lrow = tid / LPR;
+    const int lchunk = (((tid % LPR) ^ ((lrow >> SWZ_SHIFT) & (LPR - 1))) * 8);  // logical chunk landing in physical chunk tid % LPR
+    int aoff[AP];
+    int aoff1[CONCAT ? AP : 1];
+    int ahw[AP];
+    const int HoWo = p.Ho * p.Wo;
+    const int C1 = p.Cin - p.C0;
+    const int b0 = m0 / HoWo;
+    const int r0 = m0 - b0 * HoWo;
+    const int ho0 = r0 / p.Wo;
+    const int wo0 = r0 - ho0 * p.Wo;
+    const float rcpW = 1.0f / (float)p.Wo, rcpH = 1.0f / (float)p.Ho;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + i * RP + lrow;
+        const int x = wo0 + i * RP + lrow;
+        const int qx = (int)(((float)x + 0.5f) * rcpW);
+        const int wo = x - qx * p.Wo;
+        const int y = ho0 + qx;
+        const int qy = (int)(((float)y + 0.5f) * rcpH);
+        const int ho = y - qy * p.Ho;
+        const int b = b0 + qy;
+        if (CONCAT) {
+            const int H0 = p.up0 ? (p.H >> 1) : p.H, W0 = p.up0 ? (p.W >> 1) : p.W;
+            const int h0 = p.up0 ? (ho >> 1) : ho, w0 = p.up0 ? (wo >> 1) : wo;
+            aoff[i] = ((b * H0 + h0) * W0 + w0) * 3 * p.C0;
+            aoff1[i] = ((b * p.H + ho) * p.W + wo) * 3 * C1;
+            ahw[i] = (m < p.M) ? 0 : (int)0x80000000;
+        } else {
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            aoff[i] = ((b * p.H + hi0) * p.W + wi0) * 3 * p.Cin;
+            ahw[i] = (m < p.M) ? ((hi0 << 16) | (wi0 & 0xffff)) : (int)0x80000000;
+        }
+    }
+    unsigned boff[BP];  // byte offset of plane 0 of weight row n, this lane's chunk
+#pragma unroll
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * RP + lrow) * 3 * p.K + lchunk) * 2);
+
+    int tap = 0, c0 = 0;
+    unsigned avoff[AP];
+    unsigned avoff1[CONCAT ? AP : 1];
+    auto set_tap = [&]() {
+        if (CONCAT) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)((aoff[i] + lchunk) * 2);
+                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)((aoff1[i] + lchunk) * 2);
+            }
+        } else {
+            const int u = tap / p.ksize, v = tap - u * p.ksize;
+            const int toff = (u * p.W + v) * 3 * p.Cin + lchunk;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                avoff[i] = ok ? (unsigned)((aoff[i] + toff) * 2) : OOB0;
+            }
+        }
+    };
+    set_tap();
+
+    int kglob = 0;
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto fetch_dma = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            unsigned char *sa = smem + buf * STAGE_B + pl * PLANE_B + wave * RPI * ROWB;
+            unsigned char *sb = sa + BM * ROWB;
+            if (CONCAT && c0 >= p.C0) {
+#pragma unroll
+                for (int i = 0; i < AP; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sa + i * RP * ROWB), 16, (int)avoff1[i],
+                                                             (pl * C1 + c0 - p.C0) * 2, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < AP; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(sa + i * RP * ROWB), 16, (int)avoff[i],
+                                                             (pl * (CONCAT ? p.C0 : p.Cin) + c0) * 2, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < BP; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * RP * ROWB), 16, (int)boff[j],
+                                                         (pl * p.K + kglob) * 2, 0, 0);
+        }
+        kglob += BK;
+        c0 += BK;
+        if (c0 == p.Cin) {
+            c0 = 0;
+            ++tap;
+            if (!CONCAT) set_tap();
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int KT = p.K / BK;
+    fetch_dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int a_frag = (wr * 32 * TM + fr) * ROWB;
+    const int b_frag = BM * ROWB + (wc * 32 * TN + fr) * ROWB;
+    int foff[BK / 16];
+#pragma unroll
+    for (int s_ = 0; s_ < BK / 16; ++s_) foff[s_] = (((2 * s_ + fh) ^ ((fr >> SWZ_SHIFT) & (LPR - 1))) * 16);
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) fetch_dma(cur ^ 1);
+        const unsigned char *st = smem + cur * STAGE_B;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[pl][i] = *reinterpret_cast<const bf16x8 *>(st + pl * PLANE_B + a_frag + i * 32 * ROWB + foff[s]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[pl][j] = *reinterpret_cast<const bf16x8 *>(st + pl * PLANE_B + b_frag + j * 32 * ROWB + foff[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);  // hi*lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);  // lo*hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);  // mid*mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);  // hi*mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);  // mid*hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);  // hi*hi
+                    acc[i][j] = c;
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS, one 32-row block of every wave per pass (as conv_bf16.hip) ------------------
+    constexpr int EROWS = WR * 32;
+    constexpr int PPR = BN / 8;
+    constexpr int NPC = (EROWS * PPR + NT - 1) / NT;
+    float *C = reinterpret_cast<float *>(smem);
+    unsigned short *dstb = static_cast<unsigned short *>(p.dst);
+    const unsigned short *res = static_cast<const unsigned short *>(p.residual);
+    const size_t prow = (size_t)3 * p.Cout;  // bf16 elements per pixel
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        u32x4 rr[OUT_F32 ? 1 : NPC][3];
+        if (!OUT_F32 && res) {
+#pragma unroll
+            for (int it = 0; it < NPC; ++it) {
+                const int pc = tid + it * NT;
+                const int r = pc / PPR, ch = (pc - r * PPR) * 8;
+                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31);
+                const bool ok = pc < EROWS * PPR && m < p.M && n0 + ch < p.Cout;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    rr[it][pl] = ok ? *reinterpret_cast<const u32x4 *>(res + (size_t)m * prow + pl * p.Cout + n0 + ch)
+                                    : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        if (i > 0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = (wc * TN + j) * 32 + fr;
+            const float sc = p.scale[n0 + nl], sh = p.shift[n0 + nl];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] * sc + sh;
+                if (p.leaky) v = fmaxf(v, 0.1f * v);
+                C[(wr * 32 + 4 * fh + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
+            }
+        }
+        __syncthreads();
+        if (OUT_F32) {
+            float *dst = static_cast<float *>(p.dst);
+            for (int idx = tid; idx < EROWS * BN; idx += NT) {
+                const int r = idx / BN, col = idx - r * BN;
+                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31), n = n0 + col;
+                if (m < p.M && n < p.Cout) dst[(size_t)m * p.Cout + n] = C[r * CROW + col];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NPC; ++it) {
+                const int pc = tid + it * NT;
+                const int r = pc / PPR, ch = (pc - r * PPR) * 8;
+                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31);
+                if (pc >= EROWS * PPR || m >= p.M || n0 + ch >= p.Cout) continue;   // Cout < BN only for the 32-channel conv
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(C + r * CROW + ch);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(C + r * CROW + ch + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (res) {
+                    // shortcut operand = hi + mid + lo (exact), Add([from, x]) = from + x
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float a0 = (__uint_as_float(rr[it][0][k] << 16) + __uint_as_float(rr[it][1][k] << 16)) +
+                                         __uint_as_float(rr[it][2][k] << 16);
+                        const float a1 = (__uint_as_float(rr[it][0][k] & 0xffff0000u) + __uint_as_float(rr[it][1][k] & 0xffff0000u)) +
+                                         __uint_as_float(rr[it][2][k] & 0xffff0000u);
+                        v[2 * k] = a0 + v[2 * k];
+                        v[2 * k + 1] = a1 + v[2 * k + 1];
+                    }
+                }
+                u32x4 o[3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    unsigned short h0, m0_, l0, h1, m1, l1;
+                    split3(v[2 * k], h0, m0_, l0);
+                    split3(v[2 * k + 1], h1, m1, l1);
+                    o[0][k] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    o[1][k] = (unsigned)m0_ | ((unsigned)m1 << 16);
+                    o[2][k] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<u32x4 *>(dstb + (size_t)m * prow + pl * p.Cout + n0 + ch) = o[pl];
+            }
+        }
+    }
+}
+
+// tile table: {BM, BN, waves, BK}
+static const TileInfo kTilesX3[X3_TILE_COUNT] = {
+    {128, 128, 4, 32}, {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 32}, {256, 128, 8, 32}, {256, 64, 4, 32},
+    {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 256, 8, 32},
+};
+
+TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
+
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32>
+static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
+{
+    constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
+    const size_t stages = 2 * (size_t)3 * (BM + BN) * (2 * BK);
+    const size_t ctile = (size_t)WR * 32 * (BN + 4) * sizeof(float);
+    const size_t lds = stages > ctile ? stages : ctile;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto k = conv_f32x3_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int TM, int TN, int WR, int WC, int BK>
+static hipError_t launch_tx(const ConvArgs &a, bool out_f32, hipStream_t s)
+{
+    if (a.src1)
+        return out_f32 ? launch_kx<TM, TN, WR, WC, BK, true, true>(a, s) : launch_kx<TM, TN, WR, WC, BK, true, false>(a, s);
+    return out_f32 ? launch_kx<TM, TN, WR, WC, BK, false, true>(a, s) : launch_kx<TM, TN, WR, WC, BK, false, false>(a, s);
+}
+
+hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
+{
+    if (tile < 0 || tile >= X3_TILE_COUNT) return hipErrorInvalidValue;
+    const TileInfo t = kTilesX3[tile];
+    if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
+    switch (tile) {
+        case 0: return launch_tx<2, 2, 2, 2, 32>(a, out_f32, s);
+        case 1: return launch_tx<2, 1, 2, 2, 32>(a, out_f32, s);
+        case 2: return launch_tx<1, 1, 2, 2, 32>(a, out_f32, s);
+        case 3: return launch_tx<1, 2, 2, 2, 32>(a, out_f32, s);
+        case 4: return launch_tx<2, 2, 4, 2, 32>(a, out_f32, s);
+        case 5: return launch_tx<2, 2, 4, 1, 32>(a, out_f32, s);
+        case 6: return launch_tx<2, 1, 2, 2, 64>(a, out_f32, s);
+        case 7: return launch_tx<1, 1, 2, 2, 64>(a, out_f32, s);
+        case 8: return launch_tx<2, 2, 2, 4, 32>(a, out_f32, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// First layer: fp32 image in, fp32 arithmetic (K = 27), three-plane output.
+// ---------------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_first_f32x3(const ConvArgs p, const float *__restrict__ w)
+{
+    constexpr int ROW = COUT + 4;
+    __shared__ __attribute__((aligned(16))) float tr[4][64 * ROW];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int mw = blockIdx.x * 256 + wave * 64;
+    const int m = mw + lane;
+    const int HW = p.H * p.W;
+    const bool live = m < p.M;
+    const int mm = live ? m : 0;
+    const int b = mm / HW;
+    const int r = mm - b * HW;
+    const int ho = r / p.W, wo = r - ho * p.W;
+    const float *x = static_cast<const float *>(p.src0);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[COUT / 2];
+#pragma unroll
+    for (int n = 0; n < COUT / 2; ++n) acc2[n] = f32x2{0.0f, 0.0f};
+#pragma unroll 1
+    for (int u = 0; u < 3; ++u) {
+        const int hi = ho - 1 + u;
+#pragma unroll 1
+        for (int v = 0; v < 3; ++v) {
+            const int wi = wo - 1 + v;
+            const bool ok = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float *xp = x + ((size_t)(b * p.H + (ok ? hi : 0)) * p.W + (ok ? wi : 0)) * 3;
+            float xv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xv[c] = ok ? xp[c] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *wr = w + ((u * 3 + v) * 3 + c) * COUT;
+#pragma unroll
+                for (int n = 0; n < COUT; n += 2)
+                    acc2[n / 2] = __builtin_elementwise_fma(f32x2{xv[c], xv[c]}, f32x2{wr[n], wr[n + 1]}, acc2[n / 2]);
+            }
+        }
+    }
+    float *t = tr[wave];
+#pragma unroll
+    for (int n = 0; n < COUT; n += 4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc2[(n + e) / 2][(n + e) & 1] * p.scale[n + e] + p.shift[n + e];
+            if (p.leaky) v = fmaxf(v, 0.1f * v);
+            o[e] = v;
+        }
+        *reinterpret_cast<f32x4 *>(t + lane * ROW + n) = o;
+    }
+    unsigned short *dst = static_cast<unsigned short *>(p.dst);
+    constexpr int CH = COUT / 8;
+    constexpr int PPI = 64 / CH;
+    const int c8 = lane % CH, pl_ = lane / CH;
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+        const int px = it * PPI + pl_;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(t + px * ROW + c8 * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(t + px * ROW + c8 * 8 + 4);
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        u32x4 o[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned short h0, m0_, l0, h1, m1, l1;
+            split3(v[2 * k], h0, m0_, l0);
+            split3(v[2 * k + 1], h1, m1, l1);
+            o[0][k] = (unsigned)h0 | ((unsigned)h1 << 16);
+            o[1][k] = (unsigned)m0_ | ((unsigned)m1 << 16);
+            o[2][k] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        if (mw + px < p.M) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<u32x4 *>(dst + (size_t)(mw + px) * 3 * COUT + pl * COUT + c8 * 8) = o[pl];
+        }
+    }
+}
+
+hipError_t launch_conv_first_f32x3(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s)
+{
+    if (a.Cin != 3 || a.ksize != 3 || a.stride != 1 || a.Cout != 32 || a.residual || a.src1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv_first_f32x3<32>, dim3((a.M + 255) / 256), dim3(256), 0, s, a, w_hwio_dev);
+    return hipGetLastError();
+}
+
+// three-plane -> fp32 (y3_net_read_tensor)
+__global__ __launch_bounds__(256) void x3_to_f32_kernel(const unsigned short *x, float *y, size_t npix, int C)
+{
+    const size_t n = npix * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t px = i / C;
+        const int c = (int)(i - px * C);
+        const unsigned short *q = x + px * 3 * C + c;
+        y[i] = (__uint_as_float((unsigned)q[0] << 16) + __uint_as_float((unsigned)q[C] << 16)) +
+               __uint_as_float((unsigned)q[2 * C] << 16);
+    }
+}
+
+hipError_t launch_x3_to_f32(const void *x, float *y, size_t npix, int C, hipStream_t s)
+{
+    const size_t n = npix * C;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(x3_to_f32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s,
+                       static_cast<const unsigned short *>(x), y, npix, C);
+    return hipGetLastError();
+}
+
+}  // namespace y3

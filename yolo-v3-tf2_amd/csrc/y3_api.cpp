@@ -46,6 +46,9 @@ struct ConvSlot {
     int K = 0;
     int tile = -1;             // -1: choose by heuristic at plan time
     int tile_bf16 = -1;
+    int tile_x3 = -1;
+    int cout_pad64 = 0;        // Cout rounded up to 64 (the three-plane kernel has no 32-wide N tile)
+    void *wx3_dev = nullptr;   // packed [CoutPad64][3 planes][K] bf16 (hi, mid, lo of the fp32 weights)
     float *w_dev = nullptr;    // packed [CoutPad][K] (or HWIO for the first layer)
     void *wbf_dev = nullptr;   // same, bf16 (not for the first layer)
     float *scale_dev = nullptr;
@@ -101,6 +104,34 @@ unsigned short f32_to_bf16_rne(float f)
     memcpy(&u, &f, 4);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+float bf16_to_f32(unsigned short h)
+{
+    unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int choose_tile_x3(const ConvSlot &c, long long M)
+{
+    std::vector<int> cand;
+    if (c.cout_pad64 % 128 == 0)
+        cand = {0, 3, 2};
+    else
+        cand = {1, 2};
+    int best = cand.back();
+    for (int t : cand) {
+        y3::TileInfo s = y3::conv_x3_tile_info(t);
+        if (c.cout_pad64 % s.bn) continue;
+        long long blocks = ((M + s.bm - 1) / s.bm) * (c.cout_pad64 / s.bn);
+        if (blocks >= 512) {
+            best = t;
+            break;
+        }
+    }
+    return best;
 }
 
 int choose_tile_bf16(const ConvSlot &c, long long M)
@@ -198,6 +229,7 @@ y3_status y3_net_create(const y3_tensor_desc *tensors, int n_tensors, const int3
             return fail(Y3_ERR_INVALID, "y3_net_create: conv %d unsupported or inconsistent (check %d)", i, err);
         }
         c.cout_pad = (d.cout + 31) / 32 * 32;
+        c.cout_pad64 = (d.cout + 63) / 64 * 64;
         c.K = d.size * d.size * d.cin;
     }
     int ci = 0, ai = 0;
@@ -242,6 +274,7 @@ void y3_net_destroy(y3_net *net)
     for (ConvSlot &c : net->convs) {
         if (c.w_dev) (void)hipFree(c.w_dev);
         if (c.wbf_dev) (void)hipFree(c.wbf_dev);
+        if (c.wx3_dev) (void)hipFree(c.wx3_dev);
         if (c.scale_dev) (void)hipFree(c.scale_dev);
         if (c.shift_dev) (void)hipFree(c.shift_dev);
     }
@@ -257,8 +290,8 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
     const y3_conv_desc &d = c.d;
     if (d.bn ? !(gamma && beta && mean && var) : !bias)
         return fail(Y3_ERR_INVALID, "y3_net_set_conv_weights: conv %d needs %s", slot, d.bn ? "gamma/beta/mean/var" : "bias");
-    const int K = c.K, CP = c.cout_pad;
-    std::vector<float> scale(CP, 1.0f), shift(CP, 0.0f);
+    const int K = c.K, CP = c.cout_pad, CP64 = c.cout_pad64;
+    std::vector<float> scale(CP64, 1.0f), shift(CP64, 0.0f);
     for (int n = 0; n < d.cout; ++n) {
         if (d.bn) {
             // BatchNormalization inference: y = x*scale + (beta - mean*scale), scale = gamma*rsqrt(var+eps)
@@ -287,8 +320,8 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
     }
     HIP_TRY(hipSetDevice(net->device));
     if (!c.w_dev) HIP_TRY(hipMalloc(&c.w_dev, pk.size() * sizeof(float)));
-    if (!c.scale_dev) HIP_TRY(hipMalloc(&c.scale_dev, CP * sizeof(float)));
-    if (!c.shift_dev) HIP_TRY(hipMalloc(&c.shift_dev, CP * sizeof(float)));
+    if (!c.scale_dev) HIP_TRY(hipMalloc(&c.scale_dev, CP64 * sizeof(float)));
+    if (!c.shift_dev) HIP_TRY(hipMalloc(&c.shift_dev, CP64 * sizeof(float)));
     HIP_TRY(hipMemcpy(c.w_dev, (c.first_layer ? pk : pk_scaled).data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!c.first_layer) {
         std::vector<unsigned short> pb(pk.size());
@@ -296,8 +329,25 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
         if (!c.wbf_dev) HIP_TRY(hipMalloc(&c.wbf_dev, pb.size() * sizeof(unsigned short)));
         HIP_TRY(hipMemcpy(c.wbf_dev, pb.data(), pb.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMemcpy(c.scale_dev, scale.data(), CP * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c.shift_dev, shift.data(), CP * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.scale_dev, scale.data(), CP64 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.shift_dev, shift.data(), CP64 * sizeof(float), hipMemcpyHostToDevice));
+    if (!c.first_layer) {
+        // three-plane split of the (unscaled) weights: x = hi + mid + lo exactly
+        std::vector<unsigned short> px((size_t)CP64 * 3 * K, 0);
+        for (int n = 0; n < d.cout; ++n)
+            for (int k = 0; k < K; ++k) {
+                const float x = pk[(size_t)n * K + k];
+                const unsigned short h = f32_to_bf16_rne(x);
+                const float r1 = x - bf16_to_f32(h);
+                const unsigned short m = f32_to_bf16_rne(r1);
+                const float r2 = r1 - bf16_to_f32(m);
+                px[((size_t)n * 3 + 0) * K + k] = h;
+                px[((size_t)n * 3 + 1) * K + k] = m;
+                px[((size_t)n * 3 + 2) * K + k] = f32_to_bf16_rne(r2);
+            }
+        if (!c.wx3_dev) HIP_TRY(hipMalloc(&c.wx3_dev, px.size() * sizeof(unsigned short)));
+        HIP_TRY(hipMemcpy(c.wx3_dev, px.data(), px.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    }
     c.loaded = true;
     return Y3_OK;
 }
@@ -329,6 +379,20 @@ y3_status y3_net_set_tile_bf16(y3_net *net, int slot, int tile)
     return Y3_OK;
 }
 
+y3_status y3_net_set_tile_x3(y3_net *net, int slot, int tile)
+{
+    if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::X3_TILE_COUNT)
+        return fail(Y3_ERR_INVALID, "y3_net_set_tile_x3: bad argument");
+    ConvSlot &c = net->convs[slot];
+    if (tile >= 0) {
+        y3::TileInfo s = y3::conv_x3_tile_info(tile);
+        if (c.first_layer || c.cout_pad64 % s.bn || c.d.cin % s.stages || (c.d.src1 >= 0 && c.d.c0 % s.stages))
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_x3: tile does not fit this conv");
+    }
+    c.tile_x3 = tile;
+    return Y3_OK;
+}
+
 y3_status y3_net_set_lanes(y3_net *net, int lanes)
 {
     if (!net || lanes < 1 || lanes > Y3_MAX_LANES) return fail(Y3_ERR_INVALID, "y3_net_set_lanes: lanes must be in [1,%d]", Y3_MAX_LANES);
@@ -346,7 +410,8 @@ y3_status y3_net_keep_activations(y3_net *net, int keep)
 y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
 {
     if (!net || max_batch <= 0 || image_size <= 0) return fail(Y3_ERR_INVALID, "y3_net_plan: bad argument");
-    if (dtype != Y3_DTYPE_F32 && dtype != Y3_DTYPE_BF16) return fail(Y3_ERR_INVALID, "y3_net_plan: unknown dtype %d", dtype);
+    if (dtype != Y3_DTYPE_F32 && dtype != Y3_DTYPE_BF16 && dtype != Y3_DTYPE_F32X3)
+        return fail(Y3_ERR_INVALID, "y3_net_plan: unknown dtype %d", dtype);
     for (const y3_tensor_desc &t : net->tensors)
         if (t.div <= 0 || image_size % t.div) return fail(Y3_ERR_INVALID, "y3_net_plan: image_size %d not divisible by %d", image_size, t.div);
     HIP_TRY(hipSetDevice(net->device));
@@ -374,7 +439,7 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
     }
     for (int t = 0; t < nt; ++t) {
         const int s = image_size / net->tensors[t].div;
-        net->tbytes[t] = (size_t)max_batch * s * s * net->tensors[t].channels * (dtype == Y3_DTYPE_BF16 ? 2 : 4);
+        net->tbytes[t] = (size_t)max_batch * s * s * net->tensors[t].channels * (dtype == Y3_DTYPE_BF16 ? 2 : dtype == Y3_DTYPE_F32X3 ? 6 : 4);
         if (net->tbytes[t] >= 0xFFFFFFF0ull && first[t] >= 0)
             return fail(Y3_ERR_INVALID, "y3_net_plan: tensor %d is %zu bytes; 32-bit buffer offsets need < 4 GiB, lower max_batch", t, net->tbytes[t]);
     }
@@ -432,13 +497,15 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
         return (size_t)sp * sp * net->tensors[t].channels;
     };
     const bool bf = net->dtype == Y3_DTYPE_BF16;
+    const bool x3 = net->dtype == Y3_DTYPE_F32X3;
+    const size_t asz = bf ? 2 : x3 ? 6 : 4;   // bytes per element of an arena tensor
     auto is_out = [&](int t) { return t == net->outputs[0] || t == net->outputs[1] || t == net->outputs[2]; };
     // element size: head grids are always fp32; the image batch is fp32 when the Cin = 3 first-layer kernel reads it
     // (a model whose input feeds an MFMA conv directly hands bf16 in bf16 mode); everything else follows the plan
     auto esz = [&](int t) -> size_t {
         if (is_out(t)) return 4;
-        if (t == net->input_tensor) return (bf && net->tensors[t].channels != 3) ? 2 : 4;
-        return bf ? 2 : 4;
+        if (t == net->input_tensor) return net->tensors[t].channels != 3 ? asz : 4;
+        return asz;
     };
     auto ptr = [&](int t) -> void * {
         if (t < 0) return nullptr;
@@ -495,9 +562,17 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
             hipError_t e;
-            if (bf && c.first_layer) {
-                if (is_out(d.dst)) return fail(Y3_ERR_INVALID, "conv %d: first layer cannot be a head in bf16 mode", o.index);
-                e = y3::launch_conv_first_bf16(a, c.w_dev, s);
+            if ((bf || x3) && c.first_layer) {
+                if (is_out(d.dst)) return fail(Y3_ERR_INVALID, "conv %d: first layer cannot be a head in this mode", o.index);
+                e = bf ? y3::launch_conv_first_bf16(a, c.w_dev, s) : y3::launch_conv_first_f32x3(a, c.w_dev, s);
+            } else if (x3) {
+                a.wpk = c.wx3_dev;
+                a.CoutPad = c.cout_pad64;
+                a.w_bytes = (unsigned)((size_t)c.cout_pad64 * 3 * c.K * 2);
+                const bool out_f32 = is_out(d.dst);
+                if (d.residual >= 0 && out_f32) return fail(Y3_ERR_INVALID, "conv %d: residual on a head output is not supported in this mode", o.index);
+                const int tile = c.tile_x3 >= 0 ? c.tile_x3 : choose_tile_x3(c, a.M);
+                e = y3::launch_conv_f32x3(a, tile, out_f32, s);
             } else if (bf) {
                 a.wpk = c.wbf_dev;
                 a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * 2);
@@ -520,7 +595,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 if (o.index < n_ms) ms_out[o.index] = ms;
             }
         } else {
-            if (bf) return fail(Y3_ERR_INVALID, "stand-alone add/upsample/concat ops are fp32 only");
+            if (bf || x3) return fail(Y3_ERR_INVALID, "stand-alone add/upsample/concat ops are fp32 only");
             const y3_aux_desc &x = net->aux[o.index];
             const int sp = spatial(net, x.dst);
             const int C = net->tensors[x.dst].channels;
@@ -617,6 +692,11 @@ y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size
     if (n_elems) *n_elems = n;
     if (!dst_dev) return Y3_OK;
     if (!net->tdev[t]) return fail(Y3_ERR_STATE, "y3_net_read_tensor: tensor %d is not held in the arena", t);
+    if (net->dtype == Y3_DTYPE_F32X3) {
+        hipError_t e = y3::launch_x3_to_f32(net->tdev[t], dst_dev, (size_t)batch * sp * sp, net->tensors[t].channels, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_read_tensor: %s", hipGetErrorString(e));
+        return Y3_OK;
+    }
     if (net->dtype == Y3_DTYPE_BF16) {
         hipError_t e = y3::launch_bf16_to_f32(net->tdev[t], dst_dev, n, (hipStream_t)stream);
         if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_read_tensor: %s", hipGetErrorString(e));

@@ -104,11 +104,15 @@ class Net:
     def set_tile(self, slot: int, tile: int):
         check(self.lib.y3_net_set_tile(self._h, slot, tile), "y3_net_set_tile")
 
+    def set_tile_x3(self, slot: int, tile: int):
+        check(self.lib.y3_net_set_tile_x3(self._h, slot, tile), "y3_net_set_tile_x3")
+
     def set_tile_bf16(self, slot: int, tile: int):
         check(self.lib.y3_net_set_tile_bf16(self._h, slot, tile), "y3_net_set_tile_bf16")
 
     def plan(self, max_batch: int, image_size: int, dtype: Optional[int] = None):
-        """dtype: _lib.Y3_DTYPE_F32 (default) or _lib.Y3_DTYPE_BF16 (bf16 activations/weights, fp32 accumulate)."""
+        """dtype: _lib.Y3_DTYPE_F32 (default, fp32 MFMA), _lib.Y3_DTYPE_F32X3 (fp32-accurate on the bf16 matrix cores:
+        three bf16 planes per value) or _lib.Y3_DTYPE_BF16 (bf16 activations/weights, fp32 accumulate)."""
         if dtype is None:
             dtype = self.dtype
         check(self.lib.y3_net_plan(self._h, max_batch, image_size, dtype), "y3_net_plan")
@@ -126,9 +130,11 @@ class Net:
         import json
         import os
         from . import PACKAGE_DIR
-        name = f"{'bf16' if self.dtype == _lib.Y3_DTYPE_BF16 else 'f32'}_b{self.max_batch}_s{self.image_size}.json"
+        tag = {_lib.Y3_DTYPE_F32: "f32", _lib.Y3_DTYPE_BF16: "bf16", _lib.Y3_DTYPE_F32X3: "f32x3"}[self.dtype]
+        name = f"{tag}_b{self.max_batch}_s{self.image_size}.json"
         path = os.path.join(PACKAGE_DIR, "tuning", name)
-        setter = self.set_tile_bf16 if self.dtype == _lib.Y3_DTYPE_BF16 else self.set_tile
+        setter = {_lib.Y3_DTYPE_F32: self.set_tile, _lib.Y3_DTYPE_BF16: self.set_tile_bf16,
+                  _lib.Y3_DTYPE_F32X3: self.set_tile_x3}[self.dtype]
         table = {}
         if os.path.exists(path) and not os.environ.get("Y3_NO_TUNING"):
             with open(path) as f:
@@ -147,9 +153,14 @@ class Net:
         _need_cuda(images)
         cin = self.program.tensors[self.program.input_tensor].channels
         # bf16 plan + an input that feeds an MFMA conv directly (layer tests): the input is bf16 as well
-        want = torch.bfloat16 if (self.dtype == _lib.Y3_DTYPE_BF16 and cin != 3) else torch.float32
-        if images.dtype != want or images.dim() != 4 or images.shape[3] != cin or images.shape[1] != images.shape[2]:
-            raise Y3Error(f"images must be {want} [B,S,S,{cin}]")
+        if self.dtype == _lib.Y3_DTYPE_F32X3 and cin != 3:
+            # layer tests: an input feeding an MFMA conv directly is handed over as three bf16 planes [B,S,S,3,C]
+            if images.dtype != torch.bfloat16 or images.dim() != 5 or images.shape[3] != 3 or images.shape[4] != cin:
+                raise Y3Error(f"images must be bfloat16 [B,S,S,3,{cin}] (split3_planes) in the three-plane mode")
+        else:
+            want = torch.bfloat16 if (self.dtype == _lib.Y3_DTYPE_BF16 and cin != 3) else torch.float32
+            if images.dtype != want or images.dim() != 4 or images.shape[3] != cin or images.shape[1] != images.shape[2]:
+                raise Y3Error(f"images must be {want} [B,S,S,{cin}]")
         B, S = images.shape[0], images.shape[1]
         if S != self.image_size or B > self.max_batch:
             self.plan(max(B, self.max_batch), S)
@@ -247,6 +258,15 @@ def class_scores(conf, probs):
     check(_lib.load().y3_class_scores(_dev(conf), _dev(probs), B, N, nc, _dev(cls), _dev(scores), _lib.stream_ptr()),
           "y3_class_scores")
     return cls, scores
+
+
+def split3_planes(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [...,C] -> bf16 [...,3,C] with hi + mid + lo == x exactly (the activation format of Y3_DTYPE_F32X3)."""
+    hi = x.to(torch.bfloat16)
+    r1 = x - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack([hi, mid, lo], dim=-2).contiguous()
 
 
 def preprocess_image(image: torch.Tensor, batch: torch.Tensor, slot: int):
