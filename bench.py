@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per forward (y3_net_set_lanes)")
     ap.add_argument("--dtype", choices=["f32", "f32x3", "bf16"], default="f32",
                     help="conv arithmetic: f32 (headline, fp32 MFMA) or bf16 (BASELINE config 5: bf16 MFMA, fp32 accumulate)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra f32x3 measurement appended to the f32 line")
     ap.add_argument("--graph", action="store_true", help="capture the per-batch pipeline in a HIP graph and replay it")
     ap.add_argument("--per-layer", action="store_true", help="also print the per-conv timing table to stderr")
     args = ap.parse_args()
@@ -169,6 +170,35 @@ def main():
     if os.path.exists(tf_path):   # PMC-derived HBM bytes per conv-stack pass, measured by tools/profile.sh on this workload
         with open(tf_path) as f:
             traffic = json.load(f).get("conv_stack_hbm_bytes_per_step")
+    # Extra information on the default (f32) line: the same workload in the fp32-accurate three-plane mode (bf16 matrix
+    # cores, same parity tests as f32).  Not the headline value.
+    alt = None
+    if args.dtype == "f32" and not args.no_alt and graph is None:
+        net.plan(B, S, y3lib.Y3_DTYPE_F32X3)
+        for _ in range(2):
+            step()
+        fence()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dta = time.perf_counter() - ta
+        if use_dist:
+            tt = torch.tensor([dta], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dta = float(tt.item())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            net.forward(images, out=grids)
+        e1.record()
+        torch.cuda.synchronize()
+        cms = e0.elapsed_time(e1) / args.steps
+        alt = {"dtype": "f32x3 (fp32-accurate: 3 bf16 planes per value, 6 bf16 MFMAs per fp32 product)",
+               "value": round(world * B * args.steps / dta, 2), "unit": "images/s",
+               "ms_per_step": round(dta / args.steps * 1e3, 3),
+               "conv_tflops_algorithmic": round(flops_step / (cms * 1e-3) / 1e12, 2),
+               "mfma_issued_frac_of_bf16_peak": round(6.0 * flops_step / (cms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         line = {
@@ -198,6 +228,8 @@ def main():
                 "ms_median": round(conv_ms[len(conv_ms) // 2], 3),
             },
         }
+        if alt is not None:
+            line["alt_f32x3"] = alt
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(program, weights, anchors, S)
         if args.per_layer:

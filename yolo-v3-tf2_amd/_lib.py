@@ -29,7 +29,9 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
 N_REAL_TILES = 20
 # three-plane (fp32-accurate on bf16 MFMA) kernel tiles: (BM, BN, waves, BK)
 TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), (256, 64, 4, 32),
-            (128, 64, 4, 64), (64, 64, 4, 64), (128, 256, 8, 32)]
+            (128, 64, 4, 64), (64, 64, 4, 64), (128, 256, 8, 32),
+            (128, 128, 4, 32), (256, 128, 8, 32), (128, 256, 8, 32), (128, 128, 8, 32), (128, 64, 4, 32), (64, 128, 4, 32),
+            (64, 64, 4, 32)]   # 9..11, 13..15: single LDS stage
 # bf16 kernel tiles: (BM, BN, waves, BK)
 TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
               (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64),

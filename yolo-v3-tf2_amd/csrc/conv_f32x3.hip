@@ -36,7 +36,7 @@ __device__ __forceinline__ void split3(float x, unsigned short &hi, unsigned sho
     lo = bf16_bits(r2);
 }
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32>
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2>
 __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p)
 {
     constexpr int BM = 32 * TM * WR;
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     for (int s_ = 0; s_ < BK / 16; ++s_) foff[s_] = (((2 * s_ + fh) ^ ((fr >> SWZ_SHIFT) & (LPR - 1))) * 16);
 
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) fetch_dma(cur ^ 1);
+        const int cur = (STAGES == 2) ? (kt & 1) : 0;
+        if (STAGES == 2 && kt + 1 < KT) fetch_dma(cur ^ 1);
         const unsigned char *st = smem + cur * STAGE_B;
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
@@ -217,8 +217,17 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                     acc[i][j] = c;
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (STAGES == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            __syncthreads();                       // every wave is done reading the single stage
+            if (kt + 1 < KT) {
+                fetch_dma(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
     }
 
     // ---- epilogue through LDS, one 32-row block of every wave per pass (as conv_bf16.hip) ------------------
@@ -309,20 +318,21 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
 static const TileInfo kTilesX3[X3_TILE_COUNT] = {
     {128, 128, 4, 32}, {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 32}, {256, 128, 8, 32}, {256, 64, 4, 32},
     {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 256, 8, 32},
+    {128, 128, 4, 32}, {256, 128, 8, 32}, {128, 256, 8, 32}, {128, 128, 8, 32}, {128, 64, 4, 32}, {64, 128, 4, 32}, {64, 64, 4, 32},
 };
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32>
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2>
 static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
-    const size_t stages = 2 * (size_t)3 * (BM + BN) * (2 * BK);
+    const size_t stages = STAGES * (size_t)3 * (BM + BN) * (2 * BK);
     const size_t ctile = (size_t)WR * 32 * (BN + 4) * sizeof(float);
     const size_t lds = stages > ctile ? stages : ctile;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = conv_f32x3_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32>;
+    auto k = conv_f32x3_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -334,12 +344,12 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int TM, int TN, int WR, int WC, int BK>
+template <int TM, int TN, int WR, int WC, int BK, int STAGES = 2>
 static hipError_t launch_tx(const ConvArgs &a, bool out_f32, hipStream_t s)
 {
     if (a.src1)
-        return out_f32 ? launch_kx<TM, TN, WR, WC, BK, true, true>(a, s) : launch_kx<TM, TN, WR, WC, BK, true, false>(a, s);
-    return out_f32 ? launch_kx<TM, TN, WR, WC, BK, false, true>(a, s) : launch_kx<TM, TN, WR, WC, BK, false, false>(a, s);
+        return out_f32 ? launch_kx<TM, TN, WR, WC, BK, true, true, STAGES>(a, s) : launch_kx<TM, TN, WR, WC, BK, true, false, STAGES>(a, s);
+    return out_f32 ? launch_kx<TM, TN, WR, WC, BK, false, true, STAGES>(a, s) : launch_kx<TM, TN, WR, WC, BK, false, false, STAGES>(a, s);
 }
 
 hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
@@ -357,6 +367,13 @@ hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 6: return launch_tx<2, 1, 2, 2, 64>(a, out_f32, s);
         case 7: return launch_tx<1, 1, 2, 2, 64>(a, out_f32, s);
         case 8: return launch_tx<2, 2, 2, 4, 32>(a, out_f32, s);
+        case 9: return launch_tx<2, 2, 2, 2, 32, 1>(a, out_f32, s);    // 128x128 w4, single stage (3 workgroups / CU)
+        case 10: return launch_tx<2, 2, 4, 2, 32, 1>(a, out_f32, s);   // 256x128 w8, single stage (2 / CU)
+        case 11: return launch_tx<2, 2, 2, 4, 32, 1>(a, out_f32, s);   // 128x256 w8, single stage
+        case 12: return launch_tx<2, 1, 2, 4, 32>(a, out_f32, s);      // 128x128 w8 (64x32 wave tile)
+        case 13: return launch_tx<2, 1, 2, 2, 32, 1>(a, out_f32, s);   // 128x64 w4, single stage
+        case 14: return launch_tx<1, 2, 2, 2, 32, 1>(a, out_f32, s);   // 64x128 w4, single stage
+        case 15: return launch_tx<1, 1, 2, 2, 32, 1>(a, out_f32, s);   // 64x64 w4, single stage
         default: return hipErrorInvalidValue;
     }
 }
