@@ -31,7 +31,8 @@ N_REAL_TILES = 20
 TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), (256, 64, 4, 32),
             (128, 64, 4, 64), (64, 64, 4, 64), (128, 256, 8, 32),
             (128, 128, 4, 32), (256, 128, 8, 32), (128, 256, 8, 32), (128, 128, 8, 32), (128, 64, 4, 32), (64, 128, 4, 32),
-            (64, 64, 4, 32)]   # 9..11, 13..15: single LDS stage
+            (64, 64, 4, 32),   # 9..11, 13..15: single LDS stage
+            (256, 256, 8, 16), (256, 128, 8, 16), (128, 256, 8, 16), (128, 128, 4, 16)]   # 16..19: 16-deep K stages
 # bf16 kernel tiles: (BM, BN, waves, BK)
 TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
               (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64),

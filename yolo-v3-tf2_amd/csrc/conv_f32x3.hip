@@ -42,16 +42,17 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
     constexpr int NT = 64 * WR * WC;
-    constexpr int LPR = BK / 8;        // 16-B chunks (8 bf16) per row: 4 or 8
+    constexpr int LPR = BK / 8;        // 16-B chunks (8 bf16) per row: 2, 4 or 8
     constexpr int RPI = 64 / LPR;      // rows written by one wave-wide LDS-DMA instruction
     constexpr int RP = NT / LPR;       // rows per load pass of the whole workgroup
-    constexpr int AP = BM / RP, BP = BN / RP;
-    static_assert(BM % RP == 0 && BN % RP == 0 && AP >= 1 && BP >= 1, "tile too small for the thread count");
+    constexpr int AP = (BM + RP - 1) / RP, BP = (BN + RP - 1) / RP;   // a pass may cover fewer rows than RP: whole
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must be whole wave instructions");   // waves then skip it
     constexpr int ROWB = 2 * BK;                      // LDS row bytes (64 or 128)
     constexpr int PLANE_B = (BM + BN) * ROWB;         // one plane of one stage: A rows then B rows
     constexpr int STAGE_B = 3 * PLANE_B;
     constexpr int CROW = BN + 4;
-    constexpr int SWZ_SHIFT = (LPR == 8) ? 1 : 2;     // swizzle key: (row >> SWZ_SHIFT) & (LPR - 1)
+    // swizzle key (row >> SWZ_SHIFT) & (LPR - 1): 16 consecutive rows then cover all 16 of the 16-B slots of a 256-B bank row
+    constexpr int SWZ_SHIFT = (LPR == 8) ? 1 : (LPR == 4) ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -145,18 +146,21 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
             if (CONCAT && c0 >= p.C0) {
 #pragma unroll
                 for (int i = 0; i < AP; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sa + i * RP * ROWB), 16, (int)avoff1[i],
-                                                             (pl * C1 + c0 - p.C0) * 2, 0, 0);
+                    if (i * RP + wave * RPI < BM)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sa + i * RP * ROWB), 16, (int)avoff1[i],
+                                                                 (pl * C1 + c0 - p.C0) * 2, 0, 0);
             } else {
 #pragma unroll
                 for (int i = 0; i < AP; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(sa + i * RP * ROWB), 16, (int)avoff[i],
-                                                             (pl * (CONCAT ? p.C0 : p.Cin) + c0) * 2, 0, 0);
+                    if (i * RP + wave * RPI < BM)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(sa + i * RP * ROWB), 16, (int)avoff[i],
+                                                                 (pl * (CONCAT ? p.C0 : p.Cin) + c0) * 2, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < BP; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * RP * ROWB), 16, (int)boff[j],
-                                                         (pl * p.K + kglob) * 2, 0, 0);
+                if (j * RP + wave * RPI < BN)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * RP * ROWB), 16, (int)boff[j],
+                                                             (pl * p.K + kglob) * 2, 0, 0);
         }
         kglob += BK;
         c0 += BK;
@@ -319,6 +323,7 @@ static const TileInfo kTilesX3[X3_TILE_COUNT] = {
     {128, 128, 4, 32}, {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 32}, {256, 128, 8, 32}, {256, 64, 4, 32},
     {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 256, 8, 32},
     {128, 128, 4, 32}, {256, 128, 8, 32}, {128, 256, 8, 32}, {128, 128, 8, 32}, {128, 64, 4, 32}, {64, 128, 4, 32}, {64, 64, 4, 32},
+    {256, 256, 8, 16}, {256, 128, 8, 16}, {128, 256, 8, 16}, {128, 128, 4, 16},
 };
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
@@ -374,6 +379,10 @@ hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 13: return launch_tx<2, 1, 2, 2, 32, 1>(a, out_f32, s);   // 128x64 w4, single stage
         case 14: return launch_tx<1, 2, 2, 2, 32, 1>(a, out_f32, s);   // 64x128 w4, single stage
         case 15: return launch_tx<1, 1, 2, 2, 32, 1>(a, out_f32, s);   // 64x64 w4, single stage
+        case 16: return launch_tx<4, 2, 2, 4, 16>(a, out_f32, s);      // 256x256 w8 (128x64 wave tile), BK 16
+        case 17: return launch_tx<2, 2, 4, 2, 16>(a, out_f32, s);      // 256x128 w8, BK 16 (2 workgroups / CU)
+        case 18: return launch_tx<2, 2, 2, 4, 16>(a, out_f32, s);      // 128x256 w8, BK 16
+        case 19: return launch_tx<2, 2, 2, 2, 16>(a, out_f32, s);      // 128x128 w4, BK 16 (3 workgroups / CU)
         default: return hipErrorInvalidValue;
     }
 }
