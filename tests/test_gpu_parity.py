@@ -137,7 +137,7 @@ def test_x3_conv_layers_match_fp32_oracle(rt, case):
         assert np.abs(g - r).max() <= tol, (case, float(np.abs(g - r).max()), tol)
 
 
-@pytest.mark.parametrize("tile", range(20))
+@pytest.mark.parametrize("tile", range(26))
 def test_x3_every_tile(rt, tile):
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights

@@ -40,7 +40,7 @@ def main():
     net.plan(B, S, {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3}[a.dtype])
     x = torch.rand((B, S, S, 3), device="cuda")
     TL = _lib.TILES_X3 if x3 else _lib.TILES_BF16 if bf else TILES
-    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if (i >= 8 and not x3) else "") + ("s1" if (x3 and i in (9, 10, 11, 13, 14, 15)) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
+    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if (i >= 8 and not x3) else "") + ("s1" if (x3 and i in (9, 10, 11, 13, 14, 15)) else "") + ("i" if (x3 and i >= 20) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
     tiles = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else list(range(len(TL)))
     res = {}
     for t in [-1] + tiles:

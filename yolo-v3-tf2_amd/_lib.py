@@ -32,7 +32,9 @@ TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 3
             (128, 64, 4, 64), (64, 64, 4, 64), (128, 256, 8, 32),
             (128, 128, 4, 32), (256, 128, 8, 32), (128, 256, 8, 32), (128, 128, 8, 32), (128, 64, 4, 32), (64, 128, 4, 32),
             (64, 64, 4, 32),   # 9..11, 13..15: single LDS stage
-            (256, 256, 8, 16), (256, 128, 8, 16), (128, 256, 8, 16), (128, 128, 4, 16)]   # 16..19: 16-deep K stages
+            (256, 256, 8, 16), (256, 128, 8, 16), (128, 256, 8, 16), (128, 128, 4, 16),   # 16..19: 16-deep K stages
+            (256, 128, 8, 32), (128, 256, 8, 32), (128, 128, 4, 32), (128, 128, 8, 32),   # 20..23: interleaved DMA issue
+            (256, 128, 8, 32), (128, 256, 8, 32)]                                         # 24..25: + pinned issue order
 # bf16 kernel tiles: (BM, BN, waves, BK)
 TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
               (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64),

@@ -36,7 +36,9 @@ __device__ __forceinline__ void split3(float x, unsigned short &hi, unsigned sho
     lo = bf16_bits(r2);
 }
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2>
+// ILV: the LDS-DMA instructions of the next K tile are issued one or two at a time between the MFMA groups of the
+// current tile instead of as one burst (a burst costs every wave ~100 issue cycles per instruction at the same moment).
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int ILV = 0>
 __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p)
 {
     constexpr int BM = 32 * TM * WR;
@@ -171,6 +173,37 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
         }
     };
 
+    // one LDS-DMA instruction of the next tile (pc = plane * (AP + BP) + row pass); state advances in dma_advance()
+    auto dma_piece = [&](int buf, int pc) {
+        const int pl = pc / (AP + BP), r = pc - pl * (AP + BP);
+        unsigned char *sa = smem + buf * STAGE_B + pl * PLANE_B + wave * RPI * ROWB;
+        unsigned char *sb = sa + BM * ROWB;
+        if (r < AP) {
+            if ((r + 1) * RP <= BM || r * RP + wave * RPI < BM) {
+                if (CONCAT && c0 >= p.C0)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)(sa + r * RP * ROWB), 16, (int)avoff1[r],
+                                                             (pl * C1 + c0 - p.C0) * 2, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(sa + r * RP * ROWB), 16, (int)avoff[r],
+                                                             (pl * (CONCAT ? p.C0 : p.Cin) + c0) * 2, 0, 0);
+            }
+        } else {
+            const int j = r - AP;
+            if ((j + 1) * RP <= BN || j * RP + wave * RPI < BN)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * RP * ROWB), 16, (int)boff[j],
+                                                         (pl * p.K + kglob) * 2, 0, 0);
+        }
+    };
+    auto dma_advance = [&]() {
+        kglob += BK;
+        c0 += BK;
+        if (c0 == p.Cin) {
+            c0 = 0;
+            ++tap;
+            if (!CONCAT) set_tap();
+        }
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -193,7 +226,11 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = (STAGES == 2) ? (kt & 1) : 0;
-        if (STAGES == 2 && kt + 1 < KT) fetch_dma(cur ^ 1);
+        const bool more = kt + 1 < KT;
+        if (STAGES == 2 && !ILV && more) fetch_dma(cur ^ 1);
+        constexpr int NP = 3 * (AP + BP);               // DMA instructions per tile
+        constexpr int NG = (BK / 16) * TM * TN;         // MFMA groups (6 MFMAs each) per tile
+        int grp = 0;
         const unsigned char *st = smem + cur * STAGE_B;
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
@@ -219,8 +256,26 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);  // mid*hi
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);  // hi*hi
                     acc[i][j] = c;
+                    if (ILV && STAGES == 2) {
+                        // issued on the last tile too (branch-free): it lands in the idle stage, and every address
+                        // is range-checked by its buffer descriptor
+#pragma unroll
+                        for (int pc = 0; pc < NP; ++pc)
+                            if (pc * NG / NP == s * TM * TN + i * TN + j) dma_piece(cur ^ 1, pc);
+                    }
+                    ++grp;
                 }
         }
+        (void)grp;
+        if (ILV == 2 && STAGES == 2) {
+            // pin the issue order: a few MFMAs, then one DMA instruction, repeated
+#pragma unroll
+            for (int g = 0; g < NP; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, (NG * 6) / (NP + 1), 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        if (ILV && STAGES == 2) dma_advance();
         if (STAGES == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -324,11 +379,13 @@ static const TileInfo kTilesX3[X3_TILE_COUNT] = {
     {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 256, 8, 32},
     {128, 128, 4, 32}, {256, 128, 8, 32}, {128, 256, 8, 32}, {128, 128, 8, 32}, {128, 64, 4, 32}, {64, 128, 4, 32}, {64, 64, 4, 32},
     {256, 256, 8, 16}, {256, 128, 8, 16}, {128, 256, 8, 16}, {128, 128, 4, 16},
+    {256, 128, 8, 32}, {128, 256, 8, 32}, {128, 128, 4, 32}, {128, 128, 8, 32},   // 20..23: interleaved DMA issue
+    {256, 128, 8, 32}, {128, 256, 8, 32},                                         // 24..25: + pinned order
 };
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2>
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int ILV = 0>
 static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
@@ -337,7 +394,7 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
     const size_t ctile = (size_t)WR * 32 * (BN + 4) * sizeof(float);
     const size_t lds = stages > ctile ? stages : ctile;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = conv_f32x3_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES>;
+    auto k = conv_f32x3_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES, ILV>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -349,12 +406,12 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int TM, int TN, int WR, int WC, int BK, int STAGES = 2>
+template <int TM, int TN, int WR, int WC, int BK, int STAGES = 2, int ILV = 0>
 static hipError_t launch_tx(const ConvArgs &a, bool out_f32, hipStream_t s)
 {
     if (a.src1)
-        return out_f32 ? launch_kx<TM, TN, WR, WC, BK, true, true, STAGES>(a, s) : launch_kx<TM, TN, WR, WC, BK, true, false, STAGES>(a, s);
-    return out_f32 ? launch_kx<TM, TN, WR, WC, BK, false, true, STAGES>(a, s) : launch_kx<TM, TN, WR, WC, BK, false, false, STAGES>(a, s);
+        return out_f32 ? launch_kx<TM, TN, WR, WC, BK, true, true, STAGES, ILV>(a, s) : launch_kx<TM, TN, WR, WC, BK, true, false, STAGES, ILV>(a, s);
+    return out_f32 ? launch_kx<TM, TN, WR, WC, BK, false, true, STAGES, ILV>(a, s) : launch_kx<TM, TN, WR, WC, BK, false, false, STAGES, ILV>(a, s);
 }
 
 hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
@@ -383,6 +440,12 @@ hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 17: return launch_tx<2, 2, 4, 2, 16>(a, out_f32, s);      // 256x128 w8, BK 16 (2 workgroups / CU)
         case 18: return launch_tx<2, 2, 2, 4, 16>(a, out_f32, s);      // 128x256 w8, BK 16
         case 19: return launch_tx<2, 2, 2, 2, 16>(a, out_f32, s);      // 128x128 w4, BK 16 (3 workgroups / CU)
+        case 20: return launch_tx<2, 2, 4, 2, 32, 2, 1>(a, out_f32, s);   // 256x128 w8, DMA issue interleaved with MFMA groups
+        case 21: return launch_tx<2, 2, 2, 4, 32, 2, 1>(a, out_f32, s);   // 128x256 w8, interleaved
+        case 22: return launch_tx<2, 2, 2, 2, 32, 2, 1>(a, out_f32, s);   // 128x128 w4, interleaved
+        case 23: return launch_tx<2, 1, 2, 4, 32, 2, 1>(a, out_f32, s);   // 128x128 w8, interleaved
+        case 24: return launch_tx<2, 2, 4, 2, 32, 2, 2>(a, out_f32, s);   // 256x128 w8, interleaved + pinned issue order
+        case 25: return launch_tx<2, 2, 2, 4, 32, 2, 2>(a, out_f32, s);   // 128x256 w8, interleaved + pinned
         default: return hipErrorInvalidValue;
     }
 }
