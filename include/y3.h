@@ -141,7 +141,8 @@ y3_status y3_net_profile_convs(y3_net *net, const float *images_dev, int batch, 
 /* ------------------------------------------------------------------------------------------
  * Image input stage (the step right before the path): decode_image(channels=3, dtype=float32) + tf.image.resize
  * (reference: inference.py:157-158).  image_dev: [height,width,channels] uint8 (is_uint8=1; converted with * 1/255) or
- * float32 (is_uint8=0); channels 3 or 4 (alpha dropped).  Writes the bilinear (half-pixel centres, no antialias)
+ * float32 (is_uint8=0); channels 3 or 4 (alpha dropped).  is_uint8=2 is the tfrecords source's order of operations
+ * (reference: core/load_tfrecords.py:46-48): uint8 taken as 0..255, resized, then divided by 255.  Writes the bilinear (half-pixel centres, no antialias)
  * resize to image_size x image_size into batch_dev[slot] of an NHWC fp32 batch [*,image_size,image_size,3].
  * ---------------------------------------------------------------------------------------- */
 y3_status y3_preprocess_image(const void *image_dev, int is_uint8, int height, int width, int channels,
@@ -185,6 +186,12 @@ y3_status y3_nms_padded(const float *bboxes_dev, const float *scores_dev, int ba
 y3_status y3_pack_detections(const float *bboxes_dev, const int64_t *class_idx_dev, const float *scores_dev,
                              const int32_t *selected_idx_dev, const int32_t *num_valid_dev, int batch, int n,
                              int max_out, void *packed_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TFRecord framing checksum (host): CRC-32C (Castagnoli) of a host buffer, unmasked.  The tfrecords input source
+ * (reference: core/load_tfrecords.py:97-99, tf.data.TFRecordDataset) verifies it per record.
+ * ---------------------------------------------------------------------------------------- */
+uint32_t y3_crc32c(const void *data_host, size_t nbytes);
 
 #ifdef __cplusplus
 }

@@ -51,3 +51,33 @@ def nms_stress_set(rng, B, N, dup_frac=0.05, score_scale=1.0):
         dst = rng.integers(0, N, nd)
         scores[b, dst] = scores[b, src]
     return boxes, scores
+
+
+import io  # noqa: E402
+import os  # noqa: E402
+
+
+def jpeg_bytes(rng, h, w):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=95)
+    return buf.getvalue()
+
+
+def make_tfrecord_dataset(dirpath, rng, n=5, sizes=((40, 56), (64, 64), (30, 90))):
+    from yolo_v3_tf2_amd.core import load_tfrecords as m
+    payloads, truth = [], []
+    for i in range(n):
+        h, w = sizes[i % len(sizes)]
+        k = i % 3          # 0, 1 or 2 boxes
+        lo = rng.random((k, 2)).astype(np.float32) * 0.5
+        hi = lo + 0.1 + rng.random((k, 2)).astype(np.float32) * 0.4
+        names = [[b"circle", b"square", b"no such class"][j % 3] for j in range(k)]
+        jpg = jpeg_bytes(rng, h, w)
+        payloads.append(m.make_example({"image/encoded": jpg, "image/object/class/text": names,
+                                        "image/object/bbox/xmin": lo[:, 0], "image/object/bbox/ymin": lo[:, 1],
+                                        "image/object/bbox/xmax": hi[:, 0], "image/object/bbox/ymax": hi[:, 1]}))
+        truth.append((jpg, lo, hi, names))
+    m.write_records(os.path.join(dirpath, "a_00.tfrec"), payloads[:3])
+    m.write_records(os.path.join(dirpath, "b_01.tfrec"), payloads[3:])
+    return truth

@@ -542,6 +542,23 @@ def test_preprocess_matches_host_restatement(rt, H, W, C, S):
     assert np.array_equal(batch[0].cpu().numpy(), resize_bilinear(f, S, S))
 
 
+def test_preprocess_divide_after_matches_tfrecord_host_path(rt):
+    """tfrecords source order of operations (reference core/load_tfrecords.py:46-48): resize the 0..255 values, then a
+    true divide by 255 -- GPU == parse_tfrecord_fn's NumPy arithmetic, bit for bit."""
+    from yolo_v3_tf2_amd.core.utils import resize_bilinear
+    rng = np.random.default_rng(77)
+    for (H, W, S) in ((37, 61, 32), (128, 128, 416), (500, 375, 96)):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        ref = resize_bilinear(img.astype(np.float32), S, S) / np.float32(255)
+        batch = torch.zeros((1, S, S, 3), device="cuda")
+        rt.preprocess_image(_cuda(img), batch, 0, divide_after=True)
+        got = batch[0].cpu().numpy()
+        assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+    with pytest.raises(rt.Y3Error):
+        rt.preprocess_image(_cuda(rng.random((8, 8, 3), dtype=np.float32)), torch.zeros((1, 8, 8, 3), device="cuda"), 0,
+                            divide_after=True)
+
+
 # ---------------------------------------------------------------------------------------------- end to end
 def test_end_to_end_detect(rt, program, weights, anchors):
     """image -> 5-tuple.  Two-stage bar: (i) NMS on the *device's own* boxes/scores is
@@ -642,3 +659,84 @@ def test_backbone_only_config2(rt, program, weights):
     for t_bb, o in zip(bb.outputs, outs):
         idx = [c.conv_index for c in bb.conv_ops() if c.dst == t_bb][0]
         assert torch.equal(full.read_tensor(by_index[idx], B).reshape(o.shape), o)
+
+
+def test_inference_counterpart_tfrecords_source(rt, program, weights, anchors, tmp_path):
+    """input_data_source='tfrecords' (reference inference.py:119-144): records written with the TFRecord writer, batches
+    of 2 through the GPU input stage and the detect path; per-image detections equal the oracle's on the host-parsed
+    dataset images (core/load_tfrecords.parse_tfrecords)."""
+    import os
+    import yaml
+    from oracle import oracle as O
+    from tests.helpers import make_tfrecord_dataset as make_dataset
+    from yolo_v3_tf2_amd.core.load_tfrecords import parse_tfrecords
+    from yolo_v3_tf2_amd.inference import Inference
+    from yolo_v3_tf2_amd.weights import save_weights
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config/detect_config_coco.yaml")))
+    rec_dir = tmp_path / "rec"
+    rec_dir.mkdir()
+    make_dataset(str(rec_dir), np.random.default_rng(8), n=5, sizes=((200, 260), (300, 300), (180, 420)))
+    wpath = str(tmp_path / "w.safetensors")
+    save_weights(wpath, weights)
+    S = 160
+    cfg.update(input_weights_path=wpath, output_dir=str(tmp_path / "out"), image_size=S, batch_size=2,
+               input_data_source="tfrecords", tfrecords_dir=str(rec_dir),
+               model_config_file=os.path.join(root, cfg["model_config_file"]),
+               classes_name_file=os.path.join(root, cfg["classes_name_file"]),
+               anchors_file=os.path.join(root, cfg["anchors_file"]), nms_score_threshold=0.05)
+    results = Inference()(**cfg)
+    assert len(results) == 5
+    lines = open(os.path.join(cfg["output_dir"], "detect.txt")).read().strip().splitlines()
+    assert len(lines) == 5 and all(os.path.exists(os.path.join(cfg["output_dir"], f"detect_{i}.jpg")) for i in range(5))
+    imgs = np.stack([x for x, _ in parse_tfrecords(str(rec_dir), S, 100)])
+    rb, rc, rs, rsel, rnv = O.detect(program, weights, imgs, anchors, 100, 0.5, 0.05)
+    for i, (bboxes, classes, scores, _names) in enumerate(results):
+        ob, oc, os_ = O.gather_valid(rb[i], rc[i], rs[i], rsel[i], rnv[i])
+        assert len(bboxes) == len(ob) and np.array_equal(classes, oc)
+        if len(ob):
+            assert np.abs(bboxes - ob).max() <= 1e-4 and np.abs(scores - os_).max() <= 1e-4
+
+
+def test_evaluate_driver_counters_match_oracle(rt, program, weights, anchors, tmp_path):
+    """evaluate_yolov3.evaluate on a TFRecord set: the per-class counters equal those obtained by feeding the oracle's
+    detections of the same host-parsed images through the same EvaluateDetections."""
+    import os
+    from oracle import oracle as O
+    from tests.helpers import jpeg_bytes as _jpeg
+    from yolo_v3_tf2_amd import evaluate_yolov3 as ev
+    from yolo_v3_tf2_amd.core import load_tfrecords as m
+    from yolo_v3_tf2_amd.evaluate_detections import EvaluateDetections
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(21)
+    names = [l.rstrip("\n") for l in open(os.path.join(root, "datasets/coco2012/coco.names"))]
+    payloads = []
+    for i in range(4):
+        lo = (rng.random((2, 2)) * 0.5).astype(np.float32)
+        hi = lo + 0.3
+        payloads.append(m.make_example({"image/encoded": _jpeg(rng, 120, 150),
+                                        "image/object/class/text": [names[i].encode(), names[i + 7].encode()],
+                                        "image/object/bbox/xmin": lo[:, 0], "image/object/bbox/ymin": lo[:, 1],
+                                        "image/object/bbox/xmax": hi[:, 0], "image/object/bbox/ymax": hi[:, 1]}))
+    m.write_records(str(tmp_path / "set.tfrec"), payloads)
+    S = 128
+    cfg = dict(tfrecords_dir=str(tmp_path), image_size=S, batch_size=2, yolo_max_boxes=100, nms_iou_threshold=0.5,
+               classes_name_file=os.path.join(root, "datasets/coco2012/coco.names"),
+               anchors_file=os.path.join(root, "datasets/coco2012/anchors.txt"),
+               model_config_file=os.path.join(root, "config/models/yolov3/model.yaml"))
+    res = ev.evaluate(cfg, [0.05, 0.3], evaluate_iou_threshold=0.1, weights=weights)
+    assert [r[0] for r in res] == [0.05, 0.3]
+    data = list(m.parse_tfrecords(str(tmp_path), S, 100, cfg["classes_name_file"]))
+    imgs = np.stack([x for x, _ in data])
+    for thr, recall, precision, counters, one in res:
+        rb, rc, rs, rsel, rnv = O.detect(program, weights, imgs, anchors, 100, 0.5, thr)
+        ref, ref1 = EvaluateDetections(80, 0.1), EvaluateDetections(80, 0.1)
+        for i, (_, y) in enumerate(data):
+            y = y[y[:, 4] == 1]
+            ob, oc, _s = O.gather_valid(rb[i], rc[i], rs[i], rsel[i], rnv[i])
+            ref.evaluate(ob, oc, y[:, :4], y[:, 5].astype(np.int32))
+            ref1.evaluate(ob, np.zeros_like(oc), y[:, :4], np.zeros(len(y), np.int32))
+        for k in ("preds", "gts", "tp", "fp", "fn"):
+            assert np.array_equal(counters[k], ref.counters[k]), (thr, k)
+            assert np.array_equal(one[k], ref1.counters[k]), (thr, k)
+        assert counters["examples"] == 4 and counters["gts"].sum() == 8 and recall.shape == (80,)

@@ -91,6 +91,7 @@ SYMBOLS = {
     "y3_nms_workspace_bytes": (_sz, [_i, _i]),
     "y3_nms_padded": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "y3_pack_detections": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "y3_crc32c": (C.c_uint32, [_vp, C.c_size_t]),
 }
 
 _lib = None

@@ -46,6 +46,26 @@ def resize_bilinear(img, out_h, out_w):
     return (top + (bot - top) * yfr[:, None, None]).astype(np.float32)
 
 
+def resize_image(img, target_height, target_width):
+    """Aspect-preserving resize then centred zero padding to (target_height, target_width) -- reference
+    core/utils.py:17-28 (tf.image.resize(preserve_aspect_ratio=True) + tf.image.pad_to_bounding_box).  `img` is one
+    HWC image or an NHWC batch, float32.  Scaled size = round-half-even(min(th/h, tw/w) * (h, w)), at least 1."""
+    img = np.asarray(img, np.float32)
+    if img.ndim == 4:
+        return np.stack([resize_image(i, target_height, target_width) for i in img])
+    h, w = img.shape[0], img.shape[1]
+    scale = min(np.float32(target_height) / np.float32(h), np.float32(target_width) / np.float32(w))
+    sh = max(1, int(np.rint(scale * np.float32(h))))
+    sw = max(1, int(np.rint(scale * np.float32(w))))
+    scaled = img if (sh, sw) == (h, w) else resize_bilinear(img, sh, sw)   # same-size bilinear is the identity
+    top, left = (target_height - sh) // 2, (target_width - sw) // 2
+    if top < 0 or left < 0 or top + sh > target_height or left + sw > target_width:
+        raise ValueError("resize_image: scaled image does not fit the target")   # pad_to_bounding_box raises too
+    out = np.zeros((target_height, target_width, img.shape[2]), np.float32)
+    out[top:top + sh, left:left + sw] = scaled
+    return out
+
+
 def load_image_rgb01(path):
     """tf.image.decode_image(bytes, channels=3, dtype=float32): RGB, alpha dropped, uint8/255 -> [0,1]
     (reference: inference.py:157)."""

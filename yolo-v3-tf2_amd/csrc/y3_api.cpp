@@ -711,12 +711,44 @@ y3_status y3_preprocess_image(const void *image_dev, int is_uint8, int height, i
                               float *batch_dev, int slot, int image_size, void *stream)
 {
     if (!image_dev || !batch_dev || height <= 0 || width <= 0 || channels < 3 || channels > 4 || slot < 0 ||
-        image_size <= 0)
+        image_size <= 0 || is_uint8 < 0 || is_uint8 > 2 || (is_uint8 == 0 && ((uintptr_t)image_dev & 3)))
         return fail(Y3_ERR_INVALID, "y3_preprocess_image: bad argument (channels must be 3 or 4)");
     float *dst = batch_dev + (size_t)slot * image_size * image_size * 3;
     hipError_t e = y3::launch_resize(image_dev, is_uint8, height, width, channels, dst, image_size, (hipStream_t)stream);
     if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_preprocess_image launch: %s", hipGetErrorString(e));
     return Y3_OK;
+}
+
+// ------------------------------------------------------------------------------------------ TFRecord checksum
+uint32_t y3_crc32c(const void *data_host, size_t nbytes)
+{
+    // slicing-by-8 over the reflected Castagnoli polynomial
+    static uint32_t T[8][256];
+    static bool ready = [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+        return true;
+    }();
+    (void)ready;
+    const unsigned char *p = static_cast<const unsigned char *>(data_host);
+    uint32_t c = 0xFFFFFFFFu;
+    while (nbytes >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^ T[3][hi & 0xFF] ^
+            T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+        p += 8;
+        nbytes -= 8;
+    }
+    while (nbytes--) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF];
+    return c ^ 0xFFFFFFFFu;
 }
 
 // ------------------------------------------------------------------------------------------ decode

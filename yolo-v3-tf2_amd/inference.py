@@ -107,17 +107,47 @@ class Inference:
         out = open(detections_text_list_outfile, "a")
         model, class_names = self.build(model_config_file, classes_name_file, anchors_file, input_weights_path,
                                         yolo_max_boxes, nms_iou_threshold, nms_score_threshold, weights)
+        results = []
+        import torch
+        from . import runtime
         if input_data_source == "tfrecords":
-            raise NotImplementedError("TFRecord input needs TensorFlow's record reader; use image_file or images_dir")
-        if input_data_source == "image_file":
+            # reference: inference.py:119-144.  Records are parsed on the host (core/load_tfrecords.py); the
+            # resize(0..255 values) / 255 of parse_tfrecord_fn runs on the GPU straight into the batch tensor.  The
+            # reference's following resize_image(img, S, S) sees an S x S image: scale 1, no padding -- the identity.
+            from .core.load_tfrecords import decode_jpeg_u8, iter_examples
+            image_index = 0   # running index (the reference numbers files within a batch, overwriting earlier ones)
+            pend = []
+
+            def run_batch(images_u8):
+                nonlocal image_index
+                batch_dev = torch.empty((len(images_u8), image_size, image_size, 3), dtype=torch.float32,
+                                        device="cuda")
+                for slot, u8 in enumerate(images_u8):
+                    runtime.preprocess_image(torch.from_numpy(u8).cuda(), batch_dev, slot, divide_after=True)
+                b_boxes, b_cls, b_scores, b_sel, b_nv = (t.cpu().numpy() for t in model(batch_dev))
+                for bb, cc, ss, sel, nv, img in zip(b_boxes, b_cls, b_scores, b_sel, b_nv, batch_dev.cpu().numpy()):
+                    bboxes, classes, scores = self.gather_valid_detections_results(bb, cc, ss, sel, int(nv))
+                    classes_names = [class_names[idx] for idx in classes]
+                    annotated, detections = self.annotate(img, bboxes, classes_names, scores, font_size)
+                    self._dump_detections_text(detections, out)
+                    annotated.save(f"{output_dir}/detect_{image_index}.jpg")
+                    results.append((bboxes, classes, scores, classes_names))
+                    image_index += 1
+
+            for example in iter_examples(tfrecords_dir):
+                pend.append(decode_jpeg_u8(example["image/encoded"][0]))
+                if len(pend) == int(batch_size):
+                    run_batch(pend)
+                    pend = []
+            if pend:
+                run_batch(pend)
+            filenames = []
+        elif input_data_source == "image_file":
             filenames = [image_file_path]
         elif input_data_source == "images_dir":
             filenames = dir_filelist(images_dir, (".jpeg", ".jpg", ".png", ".bmp"))
         else:
             filenames = []
-        results = []
-        import torch
-        from . import runtime
         for image_index, file in enumerate(filenames):
             # decode on the host, then uint8 -> [0,1] -> bilinear resize on the GPU straight into the batch tensor
             # (reference: inference.py:157-158 decode_image + tf.image.resize)

@@ -269,16 +269,20 @@ def split3_planes(x: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, mid, lo], dim=-2).contiguous()
 
 
-def preprocess_image(image: torch.Tensor, batch: torch.Tensor, slot: int):
+def preprocess_image(image: torch.Tensor, batch: torch.Tensor, slot: int, divide_after: bool = False):
     """image [H,W,3|4] uint8 or float32 on the GPU -> batch[slot] ([S,S,3] fp32, values in [0,1] for uint8 input):
-    decode_image's uint8->float conversion fused with tf.image.resize's bilinear resampling."""
+    decode_image's uint8->float conversion fused with tf.image.resize's bilinear resampling.  divide_after=True is
+    the tfrecords source's order (reference: core/load_tfrecords.py:46-48): resize the 0..255 values, then / 255."""
     _need_cuda(image, batch)
     if image.dim() != 3 or image.dtype not in (torch.uint8, torch.float32) or batch.dtype != torch.float32:
         raise Y3Error("image must be [H,W,C] uint8/float32 and batch float32 [B,S,S,3]")
     if batch.dim() != 4 or batch.shape[1] != batch.shape[2] or batch.shape[3] != 3 or not (0 <= slot < batch.shape[0]):
         raise Y3Error("batch must be [B,S,S,3] and slot inside it")
     H, W, C_ = image.shape
-    check(_lib.load().y3_preprocess_image(_dev(image), int(image.dtype == torch.uint8), H, W, C_, _dev(batch), slot,
+    mode = (2 if divide_after else 1) if image.dtype == torch.uint8 else 0
+    if divide_after and mode == 0:
+        raise Y3Error("divide_after applies to uint8 images")
+    check(_lib.load().y3_preprocess_image(_dev(image), mode, H, W, C_, _dev(batch), slot,
                                           batch.shape[1], _lib.stream_ptr()), "y3_preprocess_image")
     return batch
 
