@@ -53,9 +53,10 @@ def main():
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per forward (y3_net_set_lanes)")
-    ap.add_argument("--dtype", choices=["f32", "f32x3", "bf16"], default="f32",
-                    help="conv arithmetic: f32 (headline, fp32 MFMA) or bf16 (BASELINE config 5: bf16 MFMA, fp32 accumulate)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra f32x3 measurement appended to the f32 line")
+    ap.add_argument("--dtype", choices=["f32", "f32x3", "f32x2", "bf16"], default="f32",
+                    help="conv arithmetic: f32 (headline, fp32 MFMA), f32x3 / f32x2 (fp32-accurate plane-split modes on the "
+                         "bf16 / fp16 matrix cores) or bf16 (BASELINE config 5: bf16 MFMA, fp32 accumulate)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra f32x3 / f32x2 measurements appended to the f32 line")
     ap.add_argument("--graph", action="store_true", help="capture the per-batch pipeline in a HIP graph and replay it")
     ap.add_argument("--per-layer", action="store_true", help="also print the per-conv timing table to stderr")
     args = ap.parse_args()
@@ -94,7 +95,8 @@ def main():
     net = runtime.Net(program)
     net.load_weights(weights)
     from yolo_v3_tf2_amd import _lib as y3lib
-    net.plan(B, S, {"f32": y3lib.Y3_DTYPE_F32, "f32x3": y3lib.Y3_DTYPE_F32X3, "bf16": y3lib.Y3_DTYPE_BF16}[args.dtype])
+    net.plan(B, S, {"f32": y3lib.Y3_DTYPE_F32, "f32x3": y3lib.Y3_DTYPE_F32X3, "f32x2": y3lib.Y3_DTYPE_F32X2,
+                    "bf16": y3lib.Y3_DTYPE_BF16}[args.dtype])
     net.set_lanes(args.lanes)
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     images = torch.rand((B, S, S, 3), generator=gen, device="cuda", dtype=torch.float32)
@@ -163,7 +165,8 @@ def main():
     flops_step = net.flops_per_image() * B
     achieved = flops_step / (conv_ms_mean * 1e-3) / 1e12
     peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-    mfma_flops_factor = 6.0 if args.dtype == "f32x3" else 1.0   # six bf16 partial products per fp32 product
+    # partial products issued per fp32 product: six bf16 (three planes) or three fp16 (two planes)
+    mfma_flops_factor = {"f32x3": 6.0, "f32x2": 3.0}.get(args.dtype, 1.0)
 
     traffic = None
     tf_path = os.path.join(ROOT, "profiles", f"r01_traffic_{args.dtype}_b{B}_s{S}.json")
@@ -172,33 +175,36 @@ def main():
             traffic = json.load(f).get("conv_stack_hbm_bytes_per_step")
     # Extra information on the default (f32) line: the same workload in the fp32-accurate three-plane mode (bf16 matrix
     # cores, same parity tests as f32).  Not the headline value.
-    alt = None
+    alts = {}
     if args.dtype == "f32" and not args.no_alt and graph is None:
-        net.plan(B, S, y3lib.Y3_DTYPE_F32X3)
-        for _ in range(2):
-            step()
-        fence()
-        ta = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dta = time.perf_counter() - ta
-        if use_dist:
-            tt = torch.tensor([dta], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dta = float(tt.item())
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.steps):
-            net.forward(images, out=grids)
-        e1.record()
-        torch.cuda.synchronize()
-        cms = e0.elapsed_time(e1) / args.steps
-        alt = {"dtype": "f32x3 (fp32-accurate: 3 bf16 planes per value, 6 bf16 MFMAs per fp32 product)",
-               "value": round(world * B * args.steps / dta, 2), "unit": "images/s",
-               "ms_per_step": round(dta / args.steps * 1e3, 3),
-               "conv_tflops_algorithmic": round(flops_step / (cms * 1e-3) / 1e12, 2),
-               "mfma_issued_frac_of_bf16_peak": round(6.0 * flops_step / (cms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
+        for tag, dt_id, factor, what in (
+                ("f32x3", y3lib.Y3_DTYPE_F32X3, 6.0, "3 bf16 planes per value, 6 bf16 MFMAs per fp32 product"),
+                ("f32x2", y3lib.Y3_DTYPE_F32X2, 3.0, "2 fp16 planes per value (2^-22 representation), 3 fp16 MFMAs per fp32 product")):
+            net.plan(B, S, dt_id)
+            for _ in range(2):
+                step()
+            fence()
+            ta = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            dta = time.perf_counter() - ta
+            if use_dist:
+                tt = torch.tensor([dta], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dta = float(tt.item())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                net.forward(images, out=grids)
+            e1.record()
+            torch.cuda.synchronize()
+            cms = e0.elapsed_time(e1) / args.steps
+            alts[tag] = {"dtype": f"{tag} (fp32-accurate, same parity tests as f32: {what})",
+                         "value": round(world * B * args.steps / dta, 2), "unit": "images/s",
+                         "ms_per_step": round(dta / args.steps * 1e3, 3),
+                         "conv_tflops_algorithmic": round(flops_step / (cms * 1e-3) / 1e12, 2),
+                         "mfma_issued_frac_of_16bit_peak": round(factor * flops_step / (cms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         line = {
@@ -214,13 +220,13 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (uniform [0,1) images, seeded random-init weights; no checkpoint ships with the reference)",
-            "config": {"workload": f"full YOLOv3 detect, {B} images/GPU, {S}x{S}, 80 classes, {'fp32' if args.dtype == 'f32' else 'bf16'} MFMA conv, "
+            "config": {"workload": f"full YOLOv3 detect, {B} images/GPU, {S}x{S}, 80 classes, { {'f32': 'fp32', 'f32x2': 'fp16 (two-plane fp32)', 'f32x3': 'bf16 (three-plane fp32)'}.get(args.dtype, 'bf16') } MFMA conv, "
                                    f"decode + class-agnostic NMS (max 100, iou 0.5, score 0.1), packed detections"
                                    + (", RCCL all-gather" if use_dist else ""),
                        "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
                        "mean_num_valid": round(nv_mean, 2)},
             "roofline": {
-                "bound": "mfma", "kernel": f"conv stack (74 x conv_{args.dtype}_mfma launches + 1 first-layer conv per step)",
+                "bound": "mfma", "kernel": f"conv stack (74 x conv_{'f32x3' if args.dtype == 'f32x2' else args.dtype}_mfma{'<2 planes>' if args.dtype == 'f32x2' else ''} launches + 1 first-layer conv per step)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved * mfma_flops_factor / peak, 4), "traffic": traffic,
                 "issued_over_algorithmic_flops": mfma_flops_factor,
@@ -228,8 +234,8 @@ def main():
                 "ms_median": round(conv_ms[len(conv_ms) // 2], 3),
             },
         }
-        if alt is not None:
-            line["alt_f32x3"] = alt
+        for tag, alt in alts.items():
+            line["alt_" + tag] = alt
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(program, weights, anchors, S)
         if args.per_layer:

@@ -38,7 +38,7 @@ enum {
 };
 
 /* activation storage / MFMA input type of the conv stack */
-enum { Y3_DTYPE_F32 = 0, Y3_DTYPE_BF16 = 1, Y3_DTYPE_F32X3 = 2 };
+enum { Y3_DTYPE_F32 = 0, Y3_DTYPE_BF16 = 1, Y3_DTYPE_F32X3 = 2, Y3_DTYPE_F32X2 = 3 };
 
 int y3_version(void);
 const char *y3_last_error(void);
@@ -109,6 +109,7 @@ y3_status y3_net_set_conv_weights(y3_net *net, int conv_slot, const float *w, co
 y3_status y3_net_set_tile(y3_net *net, int conv_slot, int tile);
 y3_status y3_net_set_tile_bf16(y3_net *net, int conv_slot, int tile);
 y3_status y3_net_set_tile_x3(y3_net *net, int conv_slot, int tile);
+y3_status y3_net_set_tile_x2(y3_net *net, int conv_slot, int tile);   /* same tile table as _x3; a subset is built */
 /* Run a forward as `lanes` (1..4) equal sub-batches on forked internal streams joined back into the caller's
  * stream: the tail of one sub-batch's conv kernel overlaps the next kernel of another.  Results are unchanged
  * (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
@@ -121,7 +122,11 @@ y3_status y3_net_keep_activations(y3_net *net, int keep);
  * epilogue); the image batch stays fp32 (the Cin = 3 first layer reads it directly) and the head grids stay fp32.
  * Y3_DTYPE_F32X3: fp32-accurate arithmetic on the bf16 matrix cores -- every value is held as three bf16 planes
  * (x = hi + mid + lo exactly) and each product uses its six leading partial products with fp32 accumulation; same
- * image / head-grid conventions, same parity bar as Y3_DTYPE_F32. */
+ * image / head-grid conventions, same parity bar as Y3_DTYPE_F32.
+ * Y3_DTYPE_F32X2: the same idea on the fp16 matrix cores with two planes per value, x = h + l' * 2^-11
+ * (h = fp16(x), l' = fp16((x - h) * 2^11)), three partial products per product (h*h, h*l', l'*h) in two fp32
+ * accumulators: representation error 2^-22 |x| (fp32: 2^-24), half the MFMAs of F32X3.  Values must stay inside the
+ * fp16 range: BN-scaled weights are checked when they are set (|w| < 65504), activations are not checked. */
 y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype);
 
 /* images_dev [B,S,S,3] fp32 -> grids_dev[3], each [B,g,g,3*(5+nc)] fp32 (== [B,g,g,3,5+nc]).

@@ -137,7 +137,7 @@ def test_x3_conv_layers_match_fp32_oracle(rt, case):
         assert np.abs(g - r).max() <= tol, (case, float(np.abs(g - r).max()), tol)
 
 
-@pytest.mark.parametrize("tile", range(26))
+@pytest.mark.parametrize("tile", range(28))
 def test_x3_every_tile(rt, tile):
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
@@ -178,6 +178,96 @@ def test_x3_network_and_detect_match_fp32_oracle(rt, program, weights, anchors, 
     torch.cuda.synchronize()
     for r, g in zip(ref, got):
         assert np.abs(g.cpu().numpy() - r).max() <= 1e-4
+    for t in probe:
+        g = net.read_tensor(t, B).cpu().numpy()
+        assert np.abs(g - kept[t]).max() <= 2e-5 * max(1.0, float(np.abs(kept[t]).max()))
+    gb, gc, gs = rt.yolo_decode_scores(got, anchors, 80)
+    gsel, gnv = rt.nms_padded(gb, gs, 100, 0.5, 0.1)
+    rb, rc, rs, rsel, rnv = O.yolo_nms(O.yolo_decode(ref, anchors, 80), 100, 0.5, 0.1)
+    assert np.abs(gb.cpu().numpy() - rb).max() <= 1e-4 and np.abs(gs.cpu().numpy() - rs).max() <= 1e-4
+    s2, n2 = O.nms_padded(gb.cpu().numpy(), gs.cpu().numpy(), 100, 0.5, 0.1)
+    assert np.array_equal(s2, gsel.cpu().numpy()) and np.array_equal(n2, gnv.cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------- f32x2
+# Two fp16 planes per value (x = h + l' * 2^-11), three fp16 MFMAs per product: representation error 2^-22 (fp32: 2^-24).
+# Held to the same tolerances as the fp32 and three-plane paths against the fp32 oracle.
+@pytest.mark.parametrize("case", range(len(CONV_CASES)))
+def test_x2_conv_layers_match_fp32_oracle(rt, case):
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    in_ch, S, B, chain, heads = CONV_CASES[case]
+    p = mini_program(in_ch, chain, heads)
+    w = synthetic_weights(p, seed=100 + case)
+    rng = np.random.default_rng(case)
+    x = (rng.standard_normal((B, S, S, in_ch)) if in_ch != 3 else rng.random((B, S, S, in_ch))).astype(np.float32)
+    ref = O.forward(p, w, x)
+    net = rt.Net(p)
+    net.load_weights(w)
+    net.plan(B, S, _lib.Y3_DTYPE_F32X2)
+    xin = _cuda(x) if in_ch == 3 else rt.split2_planes(_cuda(x))
+    got = net.forward(xin)
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        g = g.cpu().numpy().reshape(r.shape)
+        tol = 2e-5 * max(1.0, float(np.abs(r).max()))
+        assert np.abs(g - r).max() <= tol, (case, float(np.abs(g - r).max()), tol)
+
+
+def test_x2_split_is_accurate_to_2_pow_minus_22(rt):
+    x = torch.randn(4096, device="cuda") * torch.logspace(-6, 3, 4096, device="cuda")
+    pl = rt.split2_planes(x[None, :]).float()
+    back = pl[0, 0] + pl[0, 1] / 2048.0
+    big = x.abs() > 2.0 ** -13
+    assert ((back - x).abs()[big] <= 2.0 ** -22 * x.abs()[big]).all()
+    assert ((back - x).abs()[~big] <= 2.0 ** -36).all()      # lo plane subnormal: absolute error <= 2^-25 * 2^-11
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 8, 9, 10, 12, 26, 27])
+def test_x2_every_tile(rt, tile):
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    assert tile in _lib.TILES_X2_BUILT
+    bm, bn, _, bk = _lib.TILES_X3[tile]
+    p = mini_program(64, [], [dict(filters=bn, size=3), dict(filters=bn, size=1), dict(filters=bn, size=3, stride=2)])
+    w = synthetic_weights(p, seed=9)
+    x = np.random.default_rng(9).standard_normal((3, 14, 14, 64)).astype(np.float32)
+    ref = O.forward(p, w, x)
+    net = rt.Net(p)
+    net.load_weights(w)
+    for slot in range(3):
+        net.set_tile_x2(slot, tile)
+    net.plan(3, 14, _lib.Y3_DTYPE_F32X2)
+    got = net.forward(rt.split2_planes(_cuda(x)))
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        assert np.abs(g.cpu().numpy().reshape(r.shape) - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
+    with pytest.raises(rt.Y3Error):
+        net.set_tile_x2(0, 5)          # a tile id of the shared table that is not built for two planes
+
+
+@pytest.mark.parametrize("S,B", [(96, 2), (160, 1)])
+def test_x2_network_and_detect_match_fp32_oracle(rt, program, weights, anchors, S, B):
+    """Full network + decode + NMS in the two-plane mode, same bar as the three-plane mode: head logits, boxes and scores
+    within 1e-4 of the fp32 oracle, NMS bit-exact on the device's own boxes/scores."""
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    x = np.random.default_rng(1234).random((B, S, S, 3), dtype=np.float32)
+    ops = program.conv_ops()
+    probe = [ops[3].dst, ops[25].dst] + [o.dst for o in ops if o.src1 >= 0]
+    ref, kept = O.forward(program, weights, x, keep=set(probe))
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.keep_activations(True)
+    net.plan(B, S, _lib.Y3_DTYPE_F32X2)
+    got = net.forward(_cuda(x))
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        assert np.abs(g.cpu().numpy() - r).max() <= 1e-4, float(np.abs(g.cpu().numpy() - r).max())
     for t in probe:
         g = net.read_tensor(t, B).cpu().numpy()
         assert np.abs(g - kept[t]).max() <= 2e-5 * max(1.0, float(np.abs(kept[t]).max()))

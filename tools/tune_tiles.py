@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--tiles", type=str, default="all")
     ap.add_argument("--write", type=str, default="")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3"], default="f32")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3", "f32x2"], default="f32")
     a = ap.parse_args()
     B, S = a.batch, a.image_size
     p = load_program(os.path.join(ROOT, "config/models/yolov3/model.yaml"), 80)
@@ -35,13 +35,17 @@ def main():
     net = runtime.Net(p)
     net.load_weights(w)
     from yolo_v3_tf2_amd import _lib
-    bf = a.dtype in ("bf16", "f32x3")   # tile tables with a BK column
-    x3 = a.dtype == "f32x3"
-    net.plan(B, S, {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3}[a.dtype])
+    bf = a.dtype in ("bf16", "f32x3", "f32x2")   # tile tables with a BK column
+    x2 = a.dtype == "f32x2"
+    x3 = a.dtype in ("f32x3", "f32x2")            # the plane-split modes share one tile table
+    net.plan(B, S, {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3,
+                    "f32x2": _lib.Y3_DTYPE_F32X2}[a.dtype])
     x = torch.rand((B, S, S, 3), device="cuda")
     TL = _lib.TILES_X3 if x3 else _lib.TILES_BF16 if bf else TILES
-    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if (i >= 8 and not x3) else "") + ("s1" if (x3 and i in (9, 10, 11, 13, 14, 15)) else "") + ("i" if (x3 and i >= 20) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
+    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if (i >= 8 and not x3) else "") + ("s1" if (x3 and i in (9, 10, 11, 13, 14, 15)) else "") + ("i" if (x3 and 20 <= i < 26) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
     tiles = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else list(range(len(TL)))
+    if x2:
+        tiles = [t for t in tiles if t in _lib.TILES_X2_BUILT]
     res = {}
     for t in [-1] + tiles:
         bn = TL[t][1] if t >= 0 else 0
@@ -52,7 +56,7 @@ def main():
             if bf and t >= 0:
                 legal = legal and o.cin % TL[t][3] == 0 and (o.src1 < 0 or o.c0 % TL[t][3] == 0)
             ok.append(legal)
-            (net.set_tile_x3 if x3 else net.set_tile_bf16 if bf else net.set_tile)(slot, t if legal else -1)
+            (net.set_tile_x2 if x2 else net.set_tile_x3 if x3 else net.set_tile_bf16 if bf else net.set_tile)(slot, t if legal else -1)
         best = None
         for _ in range(a.reps):
             ms = net.profile_convs(x)

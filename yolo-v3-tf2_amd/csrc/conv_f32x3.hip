@@ -6,6 +6,14 @@
 // fp32-level accuracy (the parity bar of the fp32 path -- 1e-4 on boxes/scores against the fp32 oracle -- is the
 // bar of this path, same tests) at 1/6 of the bf16 MFMA rate = 2.67x the rate of v_mfma_f32_32x32x2_f32.
 //
+// A second scheme of the same kernel (NPL = 2, "f32x2") carries a value as TWO fp16 planes, x = h + l' * 2^-11 with
+// h = fp16(x) and l' = fp16((x - h) * 2^11) (the power-of-two scale keeps l' a normal number whenever |x| > 2^-13),
+// and forms a*b from three products on v_mfma_f32_32x32x16_f16:
+//      ha*hb -> accumulator 0;   ha*lb' + la'*hb -> accumulator 1;   result = acc0 + acc1 * 2^-11
+// (dropped: la*lb <= 2^-22 |a*b|; fp16 x fp16 products are exact in fp32).  Half the MFMAs and two thirds of the bytes
+// of the three-plane scheme -- it matters because both run at the socket power limit -- for a
+// representation error of 2^-22 instead of 2^-24 and a value range of |x| < 65504.
+//
 // Same fused op as conv_f32.hip / conv_bf16.hip (reference: core/parse_model.py:27-52,72,134,155-156).
 // Layout: activations [pixel][plane 0..2][C] bf16, weights [CoutPad][plane][K] bf16, head outputs fp32.
 // Operand tiles go HBM/L2 -> LDS by direct-to-LDS buffer loads (one tile per plane), double buffered; LDS rows are
@@ -20,6 +28,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
@@ -36,11 +45,62 @@ __device__ __forceinline__ void split3(float x, unsigned short &hi, unsigned sho
     lo = bf16_bits(r2);
 }
 
+// x -> (h, l') fp16 bit patterns with h + l' * 2^-11 == x up to 2^-22 |x|
+__device__ __forceinline__ void split2(float x, unsigned short &hi, unsigned short &lo)
+{
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ float f16lo(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float f16hi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+
+// eight consecutive channels: fp32 -> NPL packed planes (o[plane] = 8 x 16-bit)
+template <int NPL>
+__device__ __forceinline__ void split_planes(const float (&v)[8], u32x4 (&o)[NPL])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (NPL == 3) {
+            unsigned short h0, m0_, l0, h1, m1, l1;
+            split3(v[2 * k], h0, m0_, l0);
+            split3(v[2 * k + 1], h1, m1, l1);
+            o[0][k] = (unsigned)h0 | ((unsigned)h1 << 16);
+            o[1][k] = (unsigned)m0_ | ((unsigned)m1 << 16);
+            o[NPL - 1][k] = (unsigned)l0 | ((unsigned)l1 << 16);
+        } else {
+            unsigned short h0, l0, h1, l1;
+            split2(v[2 * k], h0, l0);
+            split2(v[2 * k + 1], h1, l1);
+            o[0][k] = (unsigned)h0 | ((unsigned)h1 << 16);
+            o[1][k] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+    }
+}
+
+// packed planes of two adjacent channels -> their fp32 values
+template <int NPL>
+__device__ __forceinline__ void join_planes(const u32x4 (&q)[NPL], int k, float &a0, float &a1)
+{
+    if (NPL == 3) {
+        a0 = (__uint_as_float(q[0][k] << 16) + __uint_as_float(q[1][k] << 16)) + __uint_as_float(q[NPL - 1][k] << 16);
+        a1 = (__uint_as_float(q[0][k] & 0xffff0000u) + __uint_as_float(q[1][k] & 0xffff0000u)) +
+             __uint_as_float(q[NPL - 1][k] & 0xffff0000u);
+    } else {
+        a0 = f16lo(q[0][k]) + f16lo(q[1][k]) * (1.0f / 2048.0f);
+        a1 = f16hi(q[0][k]) + f16hi(q[1][k]) * (1.0f / 2048.0f);
+    }
+}
+
 // ILV: the LDS-DMA instructions of the next K tile are issued one or two at a time between the MFMA groups of the
 // current tile instead of as one burst (a burst costs every wave ~100 issue cycles per instruction at the same moment).
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int ILV = 0>
+template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int ILV = 0>
 __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p)
 {
+    static_assert(NPL == 2 || NPL == 3, "two fp16 planes or three bf16 planes");
+    constexpr int NACC = NPL == 2 ? 2 : 1;   // accumulator sets (two-plane scheme: cross terms carry a 2^11 scale)
+    constexpr int MPG = NPL == 2 ? 3 : 6;    // MFMAs per (i, j, k-step) group
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
     constexpr int NT = 64 * WR * WC;
@@ -51,7 +111,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must be whole wave instructions");   // waves then skip it
     constexpr int ROWB = 2 * BK;                      // LDS row bytes (64 or 128)
     constexpr int PLANE_B = (BM + BN) * ROWB;         // one plane of one stage: A rows then B rows
-    constexpr int STAGE_B = 3 * PLANE_B;
+    constexpr int STAGE_B = NPL * PLANE_B;
     constexpr int CROW = BN + 4;
     // swizzle key (row >> SWZ_SHIFT) & (LPR - 1): 16 consecutive rows then cover all 16 of the 16-B slots of a 256-B bank row
     constexpr int SWZ_SHIFT = (LPR == 8) ? 1 : (LPR == 4) ? 2 : 3;
@@ -102,18 +162,18 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
         if (CONCAT) {
             const int H0 = p.up0 ? (p.H >> 1) : p.H, W0 = p.up0 ? (p.W >> 1) : p.W;
             const int h0 = p.up0 ? (ho >> 1) : ho, w0 = p.up0 ? (wo >> 1) : wo;
-            aoff[i] = ((b * H0 + h0) * W0 + w0) * 3 * p.C0;
-            aoff1[i] = ((b * p.H + ho) * p.W + wo) * 3 * C1;
+            aoff[i] = ((b * H0 + h0) * W0 + w0) * NPL * p.C0;
+            aoff1[i] = ((b * p.H + ho) * p.W + wo) * NPL * C1;
             ahw[i] = (m < p.M) ? 0 : (int)0x80000000;
         } else {
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-            aoff[i] = ((b * p.H + hi0) * p.W + wi0) * 3 * p.Cin;
+            aoff[i] = ((b * p.H + hi0) * p.W + wi0) * NPL * p.Cin;
             ahw[i] = (m < p.M) ? ((hi0 << 16) | (wi0 & 0xffff)) : (int)0x80000000;
         }
     }
     unsigned boff[BP];  // byte offset of plane 0 of weight row n, this lane's chunk
 #pragma unroll
-    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * RP + lrow) * 3 * p.K + lchunk) * 2);
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * RP + lrow) * NPL * p.K + lchunk) * 2);
 
     int tap = 0, c0 = 0;
     unsigned avoff[AP];
@@ -127,7 +187,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
             }
         } else {
             const int u = tap / p.ksize, v = tap - u * p.ksize;
-            const int toff = (u * p.W + v) * 3 * p.Cin + lchunk;
+            const int toff = (u * p.W + v) * NPL * p.Cin + lchunk;
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
                 const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
@@ -142,7 +202,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     typedef __attribute__((address_space(3))) void *lds_ptr;
     auto fetch_dma = [&](int buf) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
             unsigned char *sa = smem + buf * STAGE_B + pl * PLANE_B + wave * RPI * ROWB;
             unsigned char *sb = sa + BM * ROWB;
             if (CONCAT && c0 >= p.C0) {
@@ -204,13 +264,15 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[NACC][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.0f;
 
     const int KT = p.K / BK;
     fetch_dma(0);
@@ -228,34 +290,43 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
         const int cur = (STAGES == 2) ? (kt & 1) : 0;
         const bool more = kt + 1 < KT;
         if (STAGES == 2 && !ILV && more) fetch_dma(cur ^ 1);
-        constexpr int NP = 3 * (AP + BP);               // DMA instructions per tile
-        constexpr int NG = (BK / 16) * TM * TN;         // MFMA groups (6 MFMAs each) per tile
+        constexpr int NP = NPL * (AP + BP);             // DMA instructions per tile
+        constexpr int NG = (BK / 16) * TM * TN;         // MFMA groups (MPG MFMAs each) per tile
         int grp = 0;
         const unsigned char *st = smem + cur * STAGE_B;
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 fa[3][TM], fb[3][TN];
+            typedef typename std::conditional<NPL == 3, bf16x8, f16x8>::type frag_t;
+            frag_t fa[NPL][TM], fb[NPL][TN];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fa[pl][i] = *reinterpret_cast<const bf16x8 *>(st + pl * PLANE_B + a_frag + i * 32 * ROWB + foff[s]);
+                    fa[pl][i] = *reinterpret_cast<const frag_t *>(st + pl * PLANE_B + a_frag + i * 32 * ROWB + foff[s]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    fb[pl][j] = *reinterpret_cast<const bf16x8 *>(st + pl * PLANE_B + b_frag + j * 32 * ROWB + foff[s]);
+                    fb[pl][j] = *reinterpret_cast<const frag_t *>(st + pl * PLANE_B + b_frag + j * 32 * ROWB + foff[s]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);  // hi*lo
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);  // lo*hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);  // mid*mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);  // hi*mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);  // mid*hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);  // hi*hi
-                    acc[i][j] = c;
+                    if constexpr (NPL == 3) {
+                        f32x16 c = acc[0][i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);  // hi*lo
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);  // lo*hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);  // mid*mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);  // hi*mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);  // mid*hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);  // hi*hi
+                        acc[0][i][j] = c;
+                    } else {
+                        f32x16 x = acc[NACC - 1][i][j];
+                        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][j], x, 0, 0, 0);   // h*l'
+                        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][j], x, 0, 0, 0);   // l'*h
+                        acc[NACC - 1][i][j] = x;
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc[0][i][j], 0, 0, 0);  // h*h
+                    }
                     if (ILV && STAGES == 2) {
                         // issued on the last tile too (branch-free): it lands in the idle stage, and every address
                         // is range-checked by its buffer descriptor
@@ -271,7 +342,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
             // pin the issue order: a few MFMAs, then one DMA instruction, repeated
 #pragma unroll
             for (int g = 0; g < NP; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, (NG * 6) / (NP + 1), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, (NG * MPG) / (NP + 1), 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
@@ -296,10 +367,10 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     float *C = reinterpret_cast<float *>(smem);
     unsigned short *dstb = static_cast<unsigned short *>(p.dst);
     const unsigned short *res = static_cast<const unsigned short *>(p.residual);
-    const size_t prow = (size_t)3 * p.Cout;  // bf16 elements per pixel
+    const size_t prow = (size_t)NPL * p.Cout;  // 16-bit elements per pixel
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        u32x4 rr[OUT_F32 ? 1 : NPC][3];
+        u32x4 rr[OUT_F32 ? 1 : NPC][NPL];
         if (!OUT_F32 && res) {
 #pragma unroll
             for (int it = 0; it < NPC; ++it) {
@@ -308,7 +379,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                 const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31);
                 const bool ok = pc < EROWS * PPR && m < p.M && n0 + ch < p.Cout;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NPL; ++pl)
                     rr[it][pl] = ok ? *reinterpret_cast<const u32x4 *>(res + (size_t)m * prow + pl * p.Cout + n0 + ch)
                                     : u32x4{0u, 0u, 0u, 0u};
             }
@@ -320,7 +391,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
             const float sc = p.scale[n0 + nl], sh = p.shift[n0 + nl];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] * sc + sh;
+                // three planes: BN scale applied here; two planes: scale already folded into the packed weights
+                float v = NPL == 3 ? acc[0][i][j][e] * sc + sh
+                                   : (acc[0][i][j][e] + acc[NACC - 1][i][j][e] * (1.0f / 2048.0f)) + sh;
                 if (p.leaky) v = fmaxf(v, 0.1f * v);
                 C[(wr * 32 + 4 * fh + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
             }
@@ -344,29 +417,19 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                 const f32x4 v1 = *reinterpret_cast<const f32x4 *>(C + r * CROW + ch + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if (res) {
-                    // shortcut operand = hi + mid + lo (exact), Add([from, x]) = from + x
+                    // shortcut operand rebuilt from its planes, Add([from, x]) = from + x
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float a0 = (__uint_as_float(rr[it][0][k] << 16) + __uint_as_float(rr[it][1][k] << 16)) +
-                                         __uint_as_float(rr[it][2][k] << 16);
-                        const float a1 = (__uint_as_float(rr[it][0][k] & 0xffff0000u) + __uint_as_float(rr[it][1][k] & 0xffff0000u)) +
-                                         __uint_as_float(rr[it][2][k] & 0xffff0000u);
+                        float a0, a1;
+                        join_planes<NPL>(rr[it], k, a0, a1);
                         v[2 * k] = a0 + v[2 * k];
                         v[2 * k + 1] = a1 + v[2 * k + 1];
                     }
                 }
-                u32x4 o[3];
+                u32x4 o[NPL];
+                split_planes<NPL>(v, o);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    unsigned short h0, m0_, l0, h1, m1, l1;
-                    split3(v[2 * k], h0, m0_, l0);
-                    split3(v[2 * k + 1], h1, m1, l1);
-                    o[0][k] = (unsigned)h0 | ((unsigned)h1 << 16);
-                    o[1][k] = (unsigned)m0_ | ((unsigned)m1 << 16);
-                    o[2][k] = (unsigned)l0 | ((unsigned)l1 << 16);
-                }
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NPL; ++pl)
                     *reinterpret_cast<u32x4 *>(dstb + (size_t)m * prow + pl * p.Cout + n0 + ch) = o[pl];
             }
         }
@@ -381,20 +444,21 @@ static const TileInfo kTilesX3[X3_TILE_COUNT] = {
     {256, 256, 8, 16}, {256, 128, 8, 16}, {128, 256, 8, 16}, {128, 128, 4, 16},
     {256, 128, 8, 32}, {128, 256, 8, 32}, {128, 128, 4, 32}, {128, 128, 8, 32},   // 20..23: interleaved DMA issue
     {256, 128, 8, 32}, {128, 256, 8, 32},                                         // 24..25: + pinned order
+    {256, 128, 16, 32}, {128, 256, 16, 32},                                       // 26..27: 16 waves, 64x32 wave tiles
 };
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int ILV = 0>
+template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int ILV = 0>
 static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
-    const size_t stages = STAGES * (size_t)3 * (BM + BN) * (2 * BK);
+    const size_t stages = STAGES * (size_t)NPL * (BM + BN) * (2 * BK);
     const size_t ctile = (size_t)WR * 32 * (BN + 4) * sizeof(float);
     const size_t lds = stages > ctile ? stages : ctile;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = conv_f32x3_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES, ILV>;
+    auto k = conv_f32x3_mfma<NPL, TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES, ILV>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -406,12 +470,20 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+template <int NPL, int TM, int TN, int WR, int WC, int BK, int STAGES = 2, int ILV = 0>
+static hipError_t launch_tp(const ConvArgs &a, bool out_f32, hipStream_t s)
+{
+    if (a.src1)
+        return out_f32 ? launch_kx<NPL, TM, TN, WR, WC, BK, true, true, STAGES, ILV>(a, s)
+                       : launch_kx<NPL, TM, TN, WR, WC, BK, true, false, STAGES, ILV>(a, s);
+    return out_f32 ? launch_kx<NPL, TM, TN, WR, WC, BK, false, true, STAGES, ILV>(a, s)
+                   : launch_kx<NPL, TM, TN, WR, WC, BK, false, false, STAGES, ILV>(a, s);
+}
+
 template <int TM, int TN, int WR, int WC, int BK, int STAGES = 2, int ILV = 0>
 static hipError_t launch_tx(const ConvArgs &a, bool out_f32, hipStream_t s)
 {
-    if (a.src1)
-        return out_f32 ? launch_kx<TM, TN, WR, WC, BK, true, true, STAGES, ILV>(a, s) : launch_kx<TM, TN, WR, WC, BK, true, false, STAGES, ILV>(a, s);
-    return out_f32 ? launch_kx<TM, TN, WR, WC, BK, false, true, STAGES, ILV>(a, s) : launch_kx<TM, TN, WR, WC, BK, false, false, STAGES, ILV>(a, s);
+    return launch_tp<3, TM, TN, WR, WC, BK, STAGES, ILV>(a, out_f32, s);
 }
 
 hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
@@ -446,14 +518,47 @@ hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 23: return launch_tx<2, 1, 2, 4, 32, 2, 1>(a, out_f32, s);   // 128x128 w8, interleaved
         case 24: return launch_tx<2, 2, 4, 2, 32, 2, 2>(a, out_f32, s);   // 256x128 w8, interleaved + pinned issue order
         case 25: return launch_tx<2, 2, 2, 4, 32, 2, 2>(a, out_f32, s);   // 128x256 w8, interleaved + pinned
+        case 26: return launch_tx<2, 1, 4, 4, 32>(a, out_f32, s);         // 256x128 w16 (64x32 wave tile)
+        case 27: return launch_tx<2, 1, 2, 8, 32>(a, out_f32, s);         // 128x256 w16
         default: return hipErrorInvalidValue;
     }
 }
 
+// two fp16 planes: the same tile ids (a subset: the schedules that won or came close in the three-plane sweeps)
+hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
+{
+    if (tile < 0 || tile >= X3_TILE_COUNT) return hipErrorInvalidValue;
+    const TileInfo t = kTilesX3[tile];
+    if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;
+    switch (tile) {
+        case 0: return launch_tp<2, 2, 2, 2, 2, 32>(a, out_f32, s);       // 128x128 w4
+        case 1: return launch_tp<2, 2, 1, 2, 2, 32>(a, out_f32, s);       // 128x64 w4
+        case 2: return launch_tp<2, 1, 1, 2, 2, 32>(a, out_f32, s);       // 64x64 w4
+        case 3: return launch_tp<2, 1, 2, 2, 2, 32>(a, out_f32, s);       // 64x128 w4
+        case 4: return launch_tp<2, 2, 2, 4, 2, 32>(a, out_f32, s);       // 256x128 w8
+        case 6: return launch_tp<2, 2, 1, 2, 2, 64>(a, out_f32, s);       // 128x64 w4, BK 64
+        case 8: return launch_tp<2, 2, 2, 2, 4, 32>(a, out_f32, s);       // 128x256 w8
+        case 9: return launch_tp<2, 2, 2, 2, 2, 32, 1>(a, out_f32, s);    // 128x128 w4, single stage
+        case 10: return launch_tp<2, 2, 2, 4, 2, 32, 1>(a, out_f32, s);   // 256x128 w8, single stage
+        case 12: return launch_tp<2, 2, 1, 2, 4, 32>(a, out_f32, s);      // 128x128 w8
+        case 26: return launch_tp<2, 2, 1, 4, 4, 32>(a, out_f32, s);      // 256x128 w16
+        case 27: return launch_tp<2, 2, 1, 2, 8, 32>(a, out_f32, s);      // 128x256 w16
+        default: return hipErrorInvalidValue;
+    }
+}
+
+bool conv_x2_tile_built(int tile)
+{
+    switch (tile) {
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: return true;
+        default: return false;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// First layer: fp32 image in, fp32 arithmetic (K = 27), three-plane output.
+// First layer: fp32 image in, fp32 arithmetic (K = 27), plane-split output (NPL = 3: bf16 x 3, NPL = 2: fp16 x 2).
 // ---------------------------------------------------------------------------------------------------------
-template <int COUT>
+template <int COUT, int NPL>
 __global__ __launch_bounds__(256) void conv_first_f32x3(const ConvArgs p, const float *__restrict__ w)
 {
     constexpr int ROW = COUT + 4;
@@ -515,20 +620,12 @@ __global__ __launch_bounds__(256) void conv_first_f32x3(const ConvArgs p, const 
         const f32x4 v0 = *reinterpret_cast<const f32x4 *>(t + px * ROW + c8 * 8);
         const f32x4 v1 = *reinterpret_cast<const f32x4 *>(t + px * ROW + c8 * 8 + 4);
         const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        u32x4 o[3];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            unsigned short h0, m0_, l0, h1, m1, l1;
-            split3(v[2 * k], h0, m0_, l0);
-            split3(v[2 * k + 1], h1, m1, l1);
-            o[0][k] = (unsigned)h0 | ((unsigned)h1 << 16);
-            o[1][k] = (unsigned)m0_ | ((unsigned)m1 << 16);
-            o[2][k] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
+        u32x4 o[NPL];
+        split_planes<NPL>(v, o);
         if (mw + px < p.M) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                *reinterpret_cast<u32x4 *>(dst + (size_t)(mw + px) * 3 * COUT + pl * COUT + c8 * 8) = o[pl];
+            for (int pl = 0; pl < NPL; ++pl)
+                *reinterpret_cast<u32x4 *>(dst + (size_t)(mw + px) * NPL * COUT + pl * COUT + c8 * 8) = o[pl];
         }
     }
 }
@@ -536,7 +633,35 @@ __global__ __launch_bounds__(256) void conv_first_f32x3(const ConvArgs p, const 
 hipError_t launch_conv_first_f32x3(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s)
 {
     if (a.Cin != 3 || a.ksize != 3 || a.stride != 1 || a.Cout != 32 || a.residual || a.src1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(conv_first_f32x3<32>, dim3((a.M + 255) / 256), dim3(256), 0, s, a, w_hwio_dev);
+    hipLaunchKernelGGL((conv_first_f32x3<32, 3>), dim3((a.M + 255) / 256), dim3(256), 0, s, a, w_hwio_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_first_f32x2(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s)
+{
+    if (a.Cin != 3 || a.ksize != 3 || a.stride != 1 || a.Cout != 32 || a.residual || a.src1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_first_f32x3<32, 2>), dim3((a.M + 255) / 256), dim3(256), 0, s, a, w_hwio_dev);
+    return hipGetLastError();
+}
+
+// two-plane -> fp32 (y3_net_read_tensor)
+__global__ __launch_bounds__(256) void x2_to_f32_kernel(const unsigned short *x, float *y, size_t npix, int C)
+{
+    const size_t n = npix * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t px = i / C;
+        const int c = (int)(i - px * C);
+        const unsigned short *q = x + px * 2 * C + c;
+        y[i] = f16lo(q[0]) + f16lo(q[C]) * (1.0f / 2048.0f);
+    }
+}
+
+hipError_t launch_x2_to_f32(const void *x, float *y, size_t npix, int C, hipStream_t s)
+{
+    const size_t n = npix * C;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(x2_to_f32_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s,
+                       static_cast<const unsigned short *>(x), y, npix, C);
     return hipGetLastError();
 }
 

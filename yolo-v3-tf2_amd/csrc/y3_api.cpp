@@ -49,6 +49,8 @@ struct ConvSlot {
     int tile_x3 = -1;
     int cout_pad64 = 0;        // Cout rounded up to 64 (the three-plane kernel has no 32-wide N tile)
     void *wx3_dev = nullptr;   // packed [CoutPad64][3 planes][K] bf16 (hi, mid, lo of the fp32 weights)
+    int tile_x2 = -1;
+    void *wx2_dev = nullptr;   // packed [CoutPad64][2 planes][K] fp16 (h, l' = (w - h) * 2^11 of the BN-scaled weights)
     float *w_dev = nullptr;    // packed [CoutPad][K] (or HWIO for the first layer)
     void *wbf_dev = nullptr;   // same, bf16 (not for the first layer)
     float *scale_dev = nullptr;
@@ -112,6 +114,58 @@ float bf16_to_f32(unsigned short h)
     float f;
     memcpy(&f, &u, 4);
     return f;
+}
+
+// fp32 -> fp16 bits, round to nearest even, subnormals kept, >= 65520 -> inf
+unsigned short f32_to_f16_rne(float f)
+{
+    unsigned x;
+    memcpy(&x, &f, 4);
+    const unsigned short sign = (unsigned short)((x >> 16) & 0x8000u);
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return (unsigned short)(sign | 0x7e00u);
+    if (x >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);
+    if (x < 0x38800000u) {   // below 2^-14: a multiple of 2^-24
+        float a;
+        memcpy(&a, &x, 4);
+        return (unsigned short)(sign | (unsigned short)lrintf(a * 16777216.0f));
+    }
+    unsigned h = (((x >> 23) - 112u) << 10) | ((x & 0x7fffffu) >> 13);
+    const unsigned rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (unsigned short)(sign | h);
+}
+
+float f16_to_f32(unsigned short h)
+{
+    const int e = (h >> 10) & 31, m = h & 0x3ff;
+    float v;
+    if (e == 0)
+        v = ldexpf((float)m, -24);
+    else if (e == 31)
+        v = m ? NAN : INFINITY;
+    else
+        v = ldexpf((float)(1024 + m), e - 25);
+    return (h & 0x8000) ? -v : v;
+}
+
+int choose_tile_x2(const ConvSlot &c, long long M)
+{
+    // widest tile that still gives every CU at least two workgroups
+    const int cand128[] = {4, 8, 0, 3, 2}, cand64[] = {1, 2};
+    const int *cand = c.cout_pad64 % 128 == 0 ? cand128 : cand64;
+    const int n = c.cout_pad64 % 128 == 0 ? 5 : 2;
+    int best = cand[n - 1];
+    for (int k = 0; k < n; ++k) {
+        y3::TileInfo s = y3::conv_x3_tile_info(cand[k]);
+        if (c.cout_pad64 % s.bn || c.d.cin % s.stages || (c.d.src1 >= 0 && c.d.c0 % s.stages)) continue;
+        long long blocks = ((M + s.bm - 1) / s.bm) * (c.cout_pad64 / s.bn);
+        if (blocks >= 512) {
+            best = cand[k];
+            break;
+        }
+    }
+    return best;
 }
 
 int choose_tile_x3(const ConvSlot &c, long long M)
@@ -275,6 +329,7 @@ void y3_net_destroy(y3_net *net)
         if (c.w_dev) (void)hipFree(c.w_dev);
         if (c.wbf_dev) (void)hipFree(c.wbf_dev);
         if (c.wx3_dev) (void)hipFree(c.wx3_dev);
+        if (c.wx2_dev) (void)hipFree(c.wx2_dev);
         if (c.scale_dev) (void)hipFree(c.scale_dev);
         if (c.shift_dev) (void)hipFree(c.shift_dev);
     }
@@ -347,6 +402,19 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
             }
         if (!c.wx3_dev) HIP_TRY(hipMalloc(&c.wx3_dev, px.size() * sizeof(unsigned short)));
         HIP_TRY(hipMemcpy(c.wx3_dev, px.data(), px.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        // two fp16 planes of the BN-scaled weights: w = h + l' * 2^-11 (up to 2^-22 |w|); |w| must stay below 65504
+        std::vector<unsigned short> p2((size_t)CP64 * 2 * K, 0);
+        for (int n = 0; n < d.cout; ++n)
+            for (int k = 0; k < K; ++k) {
+                const float x = pk_scaled[(size_t)n * K + k];
+                if (!(fabsf(x) < 65504.0f))
+                    return fail(Y3_ERR_INVALID, "conv %d: BN-scaled weight %g is outside the fp16 range of the two-plane mode", slot, (double)x);
+                const unsigned short h = f32_to_f16_rne(x);
+                p2[((size_t)n * 2 + 0) * K + k] = h;
+                p2[((size_t)n * 2 + 1) * K + k] = f32_to_f16_rne((x - f16_to_f32(h)) * 2048.0f);
+            }
+        if (!c.wx2_dev) HIP_TRY(hipMalloc(&c.wx2_dev, p2.size() * sizeof(unsigned short)));
+        HIP_TRY(hipMemcpy(c.wx2_dev, p2.data(), p2.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     }
     c.loaded = true;
     return Y3_OK;
@@ -393,6 +461,21 @@ y3_status y3_net_set_tile_x3(y3_net *net, int slot, int tile)
     return Y3_OK;
 }
 
+y3_status y3_net_set_tile_x2(y3_net *net, int slot, int tile)
+{
+    if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::X3_TILE_COUNT)
+        return fail(Y3_ERR_INVALID, "y3_net_set_tile_x2: bad argument");
+    ConvSlot &c = net->convs[slot];
+    if (tile >= 0) {
+        y3::TileInfo s = y3::conv_x3_tile_info(tile);
+        if (!y3::conv_x2_tile_built(tile) || c.first_layer || c.cout_pad64 % s.bn || c.d.cin % s.stages ||
+            (c.d.src1 >= 0 && c.d.c0 % s.stages))
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_x2: tile does not fit this conv");
+    }
+    c.tile_x2 = tile;
+    return Y3_OK;
+}
+
 y3_status y3_net_set_lanes(y3_net *net, int lanes)
 {
     if (!net || lanes < 1 || lanes > Y3_MAX_LANES) return fail(Y3_ERR_INVALID, "y3_net_set_lanes: lanes must be in [1,%d]", Y3_MAX_LANES);
@@ -410,7 +493,7 @@ y3_status y3_net_keep_activations(y3_net *net, int keep)
 y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
 {
     if (!net || max_batch <= 0 || image_size <= 0) return fail(Y3_ERR_INVALID, "y3_net_plan: bad argument");
-    if (dtype != Y3_DTYPE_F32 && dtype != Y3_DTYPE_BF16 && dtype != Y3_DTYPE_F32X3)
+    if (dtype != Y3_DTYPE_F32 && dtype != Y3_DTYPE_BF16 && dtype != Y3_DTYPE_F32X3 && dtype != Y3_DTYPE_F32X2)
         return fail(Y3_ERR_INVALID, "y3_net_plan: unknown dtype %d", dtype);
     for (const y3_tensor_desc &t : net->tensors)
         if (t.div <= 0 || image_size % t.div) return fail(Y3_ERR_INVALID, "y3_net_plan: image_size %d not divisible by %d", image_size, t.div);
@@ -439,7 +522,7 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
     }
     for (int t = 0; t < nt; ++t) {
         const int s = image_size / net->tensors[t].div;
-        net->tbytes[t] = (size_t)max_batch * s * s * net->tensors[t].channels * (dtype == Y3_DTYPE_BF16 ? 2 : dtype == Y3_DTYPE_F32X3 ? 6 : 4);
+        net->tbytes[t] = (size_t)max_batch * s * s * net->tensors[t].channels * (dtype == Y3_DTYPE_BF16 ? 2 : dtype == Y3_DTYPE_F32X3 ? 6 : 4);   // two fp16 planes: 4 bytes as well
         if (net->tbytes[t] >= 0xFFFFFFF0ull && first[t] >= 0)
             return fail(Y3_ERR_INVALID, "y3_net_plan: tensor %d is %zu bytes; 32-bit buffer offsets need < 4 GiB, lower max_batch", t, net->tbytes[t]);
     }
@@ -498,7 +581,8 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
     };
     const bool bf = net->dtype == Y3_DTYPE_BF16;
     const bool x3 = net->dtype == Y3_DTYPE_F32X3;
-    const size_t asz = bf ? 2 : x3 ? 6 : 4;   // bytes per element of an arena tensor
+    const bool x2 = net->dtype == Y3_DTYPE_F32X2;
+    const size_t asz = bf ? 2 : x3 ? 6 : 4;   // bytes per element of an arena tensor (fp32, or 2 x fp16)
     auto is_out = [&](int t) { return t == net->outputs[0] || t == net->outputs[1] || t == net->outputs[2]; };
     // element size: head grids are always fp32; the image batch is fp32 when the Cin = 3 first-layer kernel reads it
     // (a model whose input feeds an MFMA conv directly hands bf16 in bf16 mode); everything else follows the plan
@@ -562,9 +646,18 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
             hipError_t e;
-            if ((bf || x3) && c.first_layer) {
+            if ((bf || x3 || x2) && c.first_layer) {
                 if (is_out(d.dst)) return fail(Y3_ERR_INVALID, "conv %d: first layer cannot be a head in this mode", o.index);
-                e = bf ? y3::launch_conv_first_bf16(a, c.w_dev, s) : y3::launch_conv_first_f32x3(a, c.w_dev, s);
+                e = bf ? y3::launch_conv_first_bf16(a, c.w_dev, s)
+                       : x3 ? y3::launch_conv_first_f32x3(a, c.w_dev, s) : y3::launch_conv_first_f32x2(a, c.w_dev, s);
+            } else if (x2) {
+                a.wpk = c.wx2_dev;
+                a.CoutPad = c.cout_pad64;
+                a.w_bytes = (unsigned)((size_t)c.cout_pad64 * 2 * c.K * 2);
+                const bool out_f32 = is_out(d.dst);
+                if (d.residual >= 0 && out_f32) return fail(Y3_ERR_INVALID, "conv %d: residual on a head output is not supported in this mode", o.index);
+                const int tile = c.tile_x2 >= 0 ? c.tile_x2 : choose_tile_x2(c, a.M);
+                e = y3::launch_conv_f32x2(a, tile, out_f32, s);
             } else if (x3) {
                 a.wpk = c.wx3_dev;
                 a.CoutPad = c.cout_pad64;
@@ -595,7 +688,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 if (o.index < n_ms) ms_out[o.index] = ms;
             }
         } else {
-            if (bf || x3) return fail(Y3_ERR_INVALID, "stand-alone add/upsample/concat ops are fp32 only");
+            if (bf || x3 || x2) return fail(Y3_ERR_INVALID, "stand-alone add/upsample/concat ops are fp32 only");
             const y3_aux_desc &x = net->aux[o.index];
             const int sp = spatial(net, x.dst);
             const int C = net->tensors[x.dst].channels;
@@ -692,6 +785,11 @@ y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size
     if (n_elems) *n_elems = n;
     if (!dst_dev) return Y3_OK;
     if (!net->tdev[t]) return fail(Y3_ERR_STATE, "y3_net_read_tensor: tensor %d is not held in the arena", t);
+    if (net->dtype == Y3_DTYPE_F32X2) {
+        hipError_t e = y3::launch_x2_to_f32(net->tdev[t], dst_dev, (size_t)batch * sp * sp, net->tensors[t].channels, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_read_tensor: %s", hipGetErrorString(e));
+        return Y3_OK;
+    }
     if (net->dtype == Y3_DTYPE_F32X3) {
         hipError_t e = y3::launch_x3_to_f32(net->tdev[t], dst_dev, (size_t)batch * sp * sp, net->tensors[t].channels, (hipStream_t)stream);
         if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_read_tensor: %s", hipGetErrorString(e));

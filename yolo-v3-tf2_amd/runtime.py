@@ -107,12 +107,16 @@ class Net:
     def set_tile_x3(self, slot: int, tile: int):
         check(self.lib.y3_net_set_tile_x3(self._h, slot, tile), "y3_net_set_tile_x3")
 
+    def set_tile_x2(self, slot: int, tile: int):
+        check(self.lib.y3_net_set_tile_x2(self._h, slot, tile), "y3_net_set_tile_x2")
+
     def set_tile_bf16(self, slot: int, tile: int):
         check(self.lib.y3_net_set_tile_bf16(self._h, slot, tile), "y3_net_set_tile_bf16")
 
     def plan(self, max_batch: int, image_size: int, dtype: Optional[int] = None):
         """dtype: _lib.Y3_DTYPE_F32 (default, fp32 MFMA), _lib.Y3_DTYPE_F32X3 (fp32-accurate on the bf16 matrix cores:
-        three bf16 planes per value) or _lib.Y3_DTYPE_BF16 (bf16 activations/weights, fp32 accumulate)."""
+        three bf16 planes per value), _lib.Y3_DTYPE_F32X2 (two fp16 planes per value, 2^-22 representation, |x| < 65504)
+        or _lib.Y3_DTYPE_BF16 (bf16 activations/weights, fp32 accumulate)."""
         if dtype is None:
             dtype = self.dtype
         check(self.lib.y3_net_plan(self._h, max_batch, image_size, dtype), "y3_net_plan")
@@ -130,11 +134,11 @@ class Net:
         import json
         import os
         from . import PACKAGE_DIR
-        tag = {_lib.Y3_DTYPE_F32: "f32", _lib.Y3_DTYPE_BF16: "bf16", _lib.Y3_DTYPE_F32X3: "f32x3"}[self.dtype]
+        tag = _lib.DTYPE_TAGS[self.dtype]
         name = f"{tag}_b{self.max_batch}_s{self.image_size}.json"
         path = os.path.join(PACKAGE_DIR, "tuning", name)
         setter = {_lib.Y3_DTYPE_F32: self.set_tile, _lib.Y3_DTYPE_BF16: self.set_tile_bf16,
-                  _lib.Y3_DTYPE_F32X3: self.set_tile_x3}[self.dtype]
+                  _lib.Y3_DTYPE_F32X3: self.set_tile_x3, _lib.Y3_DTYPE_F32X2: self.set_tile_x2}[self.dtype]
         table = {}
         if os.path.exists(path) and not os.environ.get("Y3_NO_TUNING"):
             with open(path) as f:
@@ -157,6 +161,9 @@ class Net:
             # layer tests: an input feeding an MFMA conv directly is handed over as three bf16 planes [B,S,S,3,C]
             if images.dtype != torch.bfloat16 or images.dim() != 5 or images.shape[3] != 3 or images.shape[4] != cin:
                 raise Y3Error(f"images must be bfloat16 [B,S,S,3,{cin}] (split3_planes) in the three-plane mode")
+        elif self.dtype == _lib.Y3_DTYPE_F32X2 and cin != 3:
+            if images.dtype != torch.float16 or images.dim() != 5 or images.shape[3] != 2 or images.shape[4] != cin:
+                raise Y3Error(f"images must be float16 [B,S,S,2,{cin}] (split2_planes) in the two-plane mode")
         else:
             want = torch.bfloat16 if (self.dtype == _lib.Y3_DTYPE_BF16 and cin != 3) else torch.float32
             if images.dtype != want or images.dim() != 4 or images.shape[3] != cin or images.shape[1] != images.shape[2]:
@@ -267,6 +274,14 @@ def split3_planes(x: torch.Tensor) -> torch.Tensor:
     mid = r1.to(torch.bfloat16)
     lo = (r1 - mid.float()).to(torch.bfloat16)
     return torch.stack([hi, mid, lo], dim=-2).contiguous()
+
+
+def split2_planes(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [...,C] -> fp16 [...,2,C]: h = fp16(x), l' = fp16((x - h) * 2^11), x == h + l' * 2^-11 up to 2^-22 |x|
+    (the activation format of Y3_DTYPE_F32X2)."""
+    h = x.to(torch.float16)
+    lo = ((x - h.float()) * 2048.0).to(torch.float16)
+    return torch.stack([h, lo], dim=-2).contiguous()
 
 
 def preprocess_image(image: torch.Tensor, batch: torch.Tensor, slot: int, divide_after: bool = False):
