@@ -22,11 +22,14 @@ def short(name):
         tm, tn, wr, wc, bk = (int(m.group(i)) for i in range(1, 6))
         return (f"conv_bf16_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},k{bk}{',cat' if m.group(6) == 'true' else ''}"
                 f"{',f32out' if m.group(7) == 'true' else ''}>")
-    m = re.search(r"conv_f32x3_mfma<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)", name)
+    m = re.search(r"conv_f32x3_mfma<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)", name)
     if m:
-        tm, tn, wr, wc, bk = (int(m.group(i)) for i in range(1, 6))
-        return (f"conv_f32x3_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},k{bk},s{m.group(8)}{',cat' if m.group(6) == 'true' else ''}"
-                f"{',f32out' if m.group(7) == 'true' else ''}>")
+        npl, tm, tn, wr, wc, bk = (int(m.group(i)) for i in range(1, 7))
+        return (f"conv_f32x{npl}_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},k{bk},s{m.group(9)}{',cat' if m.group(7) == 'true' else ''}"
+                f"{',f32out' if m.group(8) == 'true' else ''}>")
+    m = re.search(r"conv_first_f32x3<\d+, (\d)>", name)
+    if m:
+        return f"conv_first_f32x{m.group(1)}"
     for k in ("conv_first_f32x3", "conv_first_f32", "conv_first_bf16", "decode_kernel", "nms_kernel", "pack_kernel", "class_scores"):
         if k in name:
             return k
