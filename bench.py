@@ -52,7 +52,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per forward (y3_net_set_lanes)")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="concurrent sub-batches per forward (y3_net_set_lanes); 0 = what the tuning table of the mode says")
     ap.add_argument("--dtype", choices=["f32", "f32x3", "f32x2", "bf16"], default="f32",
                     help="conv arithmetic: f32 (headline, fp32 MFMA), f32x3 / f32x2 (fp32-accurate plane-split modes on the "
                          "bf16 / fp16 matrix cores) or bf16 (BASELINE config 5: bf16 MFMA, fp32 accumulate)")
@@ -97,7 +98,8 @@ def main():
     from yolo_v3_tf2_amd import _lib as y3lib
     net.plan(B, S, {"f32": y3lib.Y3_DTYPE_F32, "f32x3": y3lib.Y3_DTYPE_F32X3, "f32x2": y3lib.Y3_DTYPE_F32X2,
                     "bf16": y3lib.Y3_DTYPE_BF16}[args.dtype])
-    net.set_lanes(args.lanes)
+    if args.lanes > 0:
+        net.set_lanes(args.lanes)
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     images = torch.rand((B, S, S, 3), generator=gen, device="cuda", dtype=torch.float32)
     grids = [torch.empty((B, g, g, 3, 5 + nc), device="cuda") for g in net.grid_sizes()]

@@ -137,7 +137,7 @@ def test_x3_conv_layers_match_fp32_oracle(rt, case):
         assert np.abs(g - r).max() <= tol, (case, float(np.abs(g - r).max()), tol)
 
 
-@pytest.mark.parametrize("tile", range(28))
+@pytest.mark.parametrize("tile", list(range(28)) + [30])
 def test_x3_every_tile(rt, tile):
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
@@ -225,7 +225,7 @@ def test_x2_split_is_accurate_to_2_pow_minus_22(rt):
     assert ((back - x).abs()[~big] <= 2.0 ** -36).all()      # lo plane subnormal: absolute error <= 2^-25 * 2^-11
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 8, 9, 10, 12, 26, 27])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 8, 9, 10, 12, 26, 27, 30, 31, 32, 33])
 def test_x2_every_tile(rt, tile):
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
@@ -423,6 +423,25 @@ def test_forward_lanes_bit_identical(rt, program, weights, lanes):
     torch.cuda.synchronize()
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("mode", ["f32x3", "f32x2", "bf16"])
+def test_forward_lanes_bit_identical_other_modes(rt, program, weights, mode):
+    """Same check in the plane-split and bf16 modes, with the three unequal lanes the tuning tables use."""
+    from yolo_v3_tf2_amd import _lib
+    dt = {"f32x3": _lib.Y3_DTYPE_F32X3, "f32x2": _lib.Y3_DTYPE_F32X2, "bf16": _lib.Y3_DTYPE_BF16}[mode]
+    x = _cuda(np.random.default_rng(6).random((7, 96, 96, 3), dtype=np.float32))
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(7, 96, dt)
+    net.set_lanes(1)
+    a = [g.clone() for g in net.forward(x)]
+    for lanes in (2, 3):
+        net.set_lanes(lanes)
+        b = net.forward(x)
+        torch.cuda.synchronize()
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
 
 
 def test_full_size_batch_properties(rt, program, weights, anchors):

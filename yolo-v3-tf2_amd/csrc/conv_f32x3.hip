@@ -205,7 +205,10 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
         for (int pl = 0; pl < NPL; ++pl) {
             unsigned char *sa = smem + buf * STAGE_B + pl * PLANE_B + wave * RPI * ROWB;
             unsigned char *sb = sa + BM * ROWB;
-            if (CONCAT && c0 >= p.C0) {
+            if (ILV == 3 && tap != 0) {
+                // timing probe (results are wrong): activations fetched for the first tap only -- what would a 3x3
+                // conv gain if its A operand came from an LDS-resident halo patch instead of one L2 read per tap?
+            } else if (CONCAT && c0 >= p.C0) {
 #pragma unroll
                 for (int i = 0; i < AP; ++i)
                     if (i * RP + wave * RPI < BM)
@@ -264,6 +267,27 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
         }
     };
 
+    // three stages: while tile kt is multiplied, tiles kt+1 and kt+2 are in flight; "tile kt+1 has landed" is then
+    // "at most this wave's own DMA instructions of tile kt+2 are outstanding" (vmcnt retires in order)
+    int ndma = 0;
+    if (STAGES == 3) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) ndma += (i * RP + wave * RPI < BM) ? NPL : 0;
+#pragma unroll
+        for (int j = 0; j < BP; ++j) ndma += (j * RP + wave * RPI < BN) ? NPL : 0;
+    }
+    auto wait_all_but_newest_tile = [&]() {
+        // s_waitcnt takes an immediate: pick the matching one (wave-uniform branches)
+        if (ndma >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (ndma >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (ndma >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ndma >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ndma >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (ndma >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (ndma >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
     f32x16 acc[NACC][TM][TN];
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
@@ -276,7 +300,12 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
 
     const int KT = p.K / BK;
     fetch_dma(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STAGES == 3 && KT > 1) {
+        fetch_dma(1);
+        wait_all_but_newest_tile();
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
@@ -286,10 +315,12 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
 #pragma unroll
     for (int s_ = 0; s_ < BK / 16; ++s_) foff[s_] = (((2 * s_ + fh) ^ ((fr >> SWZ_SHIFT) & (LPR - 1))) * 16);
 
+    int cur3 = 0;   // STAGES == 3: stage of tile kt
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = (STAGES == 2) ? (kt & 1) : 0;
+        const int cur = (STAGES == 3) ? cur3 : (STAGES == 2) ? (kt & 1) : 0;
         const bool more = kt + 1 < KT;
-        if (STAGES == 2 && !ILV && more) fetch_dma(cur ^ 1);
+        if (STAGES == 2 && (!ILV || ILV == 3) && more) fetch_dma(cur ^ 1);
+        if (STAGES == 3 && kt + 2 < KT) fetch_dma(cur3 == 0 ? 2 : cur3 - 1);   // stage of tile kt-1, free since the last barrier
         constexpr int NP = NPL * (AP + BP);             // DMA instructions per tile
         constexpr int NG = (BK / 16) * TM * TN;         // MFMA groups (MPG MFMAs each) per tile
         int grp = 0;
@@ -307,27 +338,32 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                 for (int j = 0; j < TN; ++j)
                     fb[pl][j] = *reinterpret_cast<const frag_t *>(st + pl * PLANE_B + b_frag + j * 32 * ROWB + foff[s]);
             }
+            // products outermost, (i, j) innermost: consecutive MFMAs never wait on each other's accumulator
+            if constexpr (NPL == 3) {
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][i], fb[PB[q]][j], acc[0][i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)    // h*l' and l'*h into the scaled accumulator set, then h*h
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            f32x16 &c = acc[q == 2 ? 0 : NACC - 1][i][j];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[q == 1 ? 1 : 0][i], fb[q == 0 ? 1 : 0][j], c, 0, 0, 0);
+                        }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if constexpr (NPL == 3) {
-                        f32x16 c = acc[0][i][j];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);  // hi*lo
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);  // lo*hi
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);  // mid*mid
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);  // hi*mid
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);  // mid*hi
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);  // hi*hi
-                        acc[0][i][j] = c;
-                    } else {
-                        f32x16 x = acc[NACC - 1][i][j];
-                        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][j], x, 0, 0, 0);   // h*l'
-                        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][j], x, 0, 0, 0);   // l'*h
-                        acc[NACC - 1][i][j] = x;
-                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc[0][i][j], 0, 0, 0);  // h*h
-                    }
-                    if (ILV && STAGES == 2) {
+                    if (ILV && ILV != 3 && STAGES == 2) {
                         // issued on the last tile too (branch-free): it lands in the idle stage, and every address
                         // is range-checked by its buffer descriptor
 #pragma unroll
@@ -346,8 +382,15 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
-        if (ILV && STAGES == 2) dma_advance();
-        if (STAGES == 2) {
+        if (ILV && ILV != 3 && STAGES == 2) dma_advance();
+        if (STAGES == 3) {
+            if (kt + 2 < KT)
+                wait_all_but_newest_tile();
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur3 = cur3 == 2 ? 0 : cur3 + 1;
+        } else if (STAGES == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         } else {
@@ -445,6 +488,8 @@ static const TileInfo kTilesX3[X3_TILE_COUNT] = {
     {256, 128, 8, 32}, {128, 256, 8, 32}, {128, 128, 4, 32}, {128, 128, 8, 32},   // 20..23: interleaved DMA issue
     {256, 128, 8, 32}, {128, 256, 8, 32},                                         // 24..25: + pinned order
     {256, 128, 16, 32}, {128, 256, 16, 32},                                       // 26..27: 16 waves, 64x32 wave tiles
+    {256, 128, 16, 32}, {128, 128, 8, 32},                                        // 28..29: two-plane timing probes (A fetched for tap 0 only)
+    {128, 128, 8, 32}, {256, 128, 16, 32}, {256, 128, 8, 32}, {128, 256, 16, 32},  // 30..33: three LDS stages
 };
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
@@ -520,6 +565,7 @@ hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 25: return launch_tx<2, 2, 2, 4, 32, 2, 2>(a, out_f32, s);   // 128x256 w8, interleaved + pinned
         case 26: return launch_tx<2, 1, 4, 4, 32>(a, out_f32, s);         // 256x128 w16 (64x32 wave tile)
         case 27: return launch_tx<2, 1, 2, 8, 32>(a, out_f32, s);         // 128x256 w16
+        case 30: return launch_tx<2, 1, 2, 4, 32, 3>(a, out_f32, s);      // 128x128 w8, three stages
         default: return hipErrorInvalidValue;
     }
 }
@@ -543,14 +589,22 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 12: return launch_tp<2, 2, 1, 2, 4, 32>(a, out_f32, s);      // 128x128 w8
         case 26: return launch_tp<2, 2, 1, 4, 4, 32>(a, out_f32, s);      // 256x128 w16
         case 27: return launch_tp<2, 2, 1, 2, 8, 32>(a, out_f32, s);      // 128x256 w16
+        case 28: return launch_tp<2, 2, 1, 4, 4, 32, 2, 3>(a, out_f32, s);   // probe: 256x128 w16, A for tap 0 only
+        case 29: return launch_tp<2, 2, 1, 2, 4, 32, 2, 3>(a, out_f32, s);   // probe: 128x128 w8, A for tap 0 only
+        case 30: return launch_tp<2, 2, 1, 2, 4, 32, 3>(a, out_f32, s);      // 128x128 w8, three stages
+        case 31: return launch_tp<2, 2, 1, 4, 4, 32, 3>(a, out_f32, s);      // 256x128 w16, three stages
+        case 32: return launch_tp<2, 2, 2, 4, 2, 32, 3>(a, out_f32, s);      // 256x128 w8, three stages
+        case 33: return launch_tp<2, 2, 1, 2, 8, 32, 3>(a, out_f32, s);      // 128x256 w16, three stages
         default: return hipErrorInvalidValue;
     }
 }
 
+bool conv_x3_tile_built(int tile) { return (tile >= 0 && tile <= 27) || tile == 30; }
+
 bool conv_x2_tile_built(int tile)
 {
     switch (tile) {
-        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: return true;
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: return true;
         default: return false;
     }
 }

@@ -449,7 +449,7 @@ y3_status y3_net_set_tile_bf16(y3_net *net, int slot, int tile)
 
 y3_status y3_net_set_tile_x3(y3_net *net, int slot, int tile)
 {
-    if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::X3_TILE_COUNT)
+    if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::X3_TILE_COUNT || (tile >= 0 && !y3::conv_x3_tile_built(tile)))
         return fail(Y3_ERR_INVALID, "y3_net_set_tile_x3: bad argument");
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
@@ -740,13 +740,12 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
         }
     }
     HIP_TRY(hipEventRecord(net->fork_ev, s));
-    // unequal sub-batches on purpose (2 lanes: 3/8 and 5/8 of the batch): equal ones run the same kernels in lockstep,
-    // so their tails coincide and nothing fills them
+    // equal sub-batches (measured with tools/lanes_sweep.py: weighted 2:3 / 3:4:5 splits were 2-3 % slower)
     int start[Y3_MAX_LANES + 1];
     for (int l = 0; l <= lanes; ++l) start[l] = (int)((long long)batch * l / lanes);
-    if (lanes == 2 && batch >= 8) start[1] = batch * 3 / 8;
     for (int l = 0; l < lanes; ++l) {
         const int nb = start[l + 1] - start[l];
+        if (nb <= 0) continue;
         HIP_TRY(hipStreamWaitEvent(net->lane_stream[l], net->fork_ev, 0));
         y3_status st = run_slice(net, images, grids, start[l], nb, net->lane_stream[l], nullptr, 0, l, lanes);
         if (st != Y3_OK) return st;

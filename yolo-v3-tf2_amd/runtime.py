@@ -139,10 +139,13 @@ class Net:
         path = os.path.join(PACKAGE_DIR, "tuning", name)
         setter = {_lib.Y3_DTYPE_F32: self.set_tile, _lib.Y3_DTYPE_BF16: self.set_tile_bf16,
                   _lib.Y3_DTYPE_F32X3: self.set_tile_x3, _lib.Y3_DTYPE_F32X2: self.set_tile_x2}[self.dtype]
-        table = {}
+        table, lanes = {}, 1
         if os.path.exists(path) and not os.environ.get("Y3_NO_TUNING"):
             with open(path) as f:
-                table = json.load(f).get("tiles", {})
+                doc = json.load(f)
+            table, lanes = doc.get("tiles", {}), int(doc.get("lanes", 1))
+        # concurrent sub-batches (tools/lanes_sweep.py): the tail of one sub-batch's kernel overlaps another's bulk
+        self.set_lanes(lanes)
         for slot, o in enumerate(self.conv_ops):
             if o.cin == 3:
                 continue
