@@ -34,7 +34,7 @@ def cpu_baseline(program, weights, anchors, image_size, budget_s=20.0):
     t0 = time.time()
     O.detect(program, weights, x1, anchors)
     t1 = time.time() - t0
-    n = int(max(1, min(8, budget_s // max(t1, 1e-3) - 1)))
+    n = int(max(1, min(32, budget_s // max(t1, 1e-3) - 1)))
     xn = np.random.default_rng(1235).random((n, image_size, image_size, 3), dtype=np.float32)
     t0 = time.time()
     O.detect(program, weights, xn, anchors)
