@@ -319,7 +319,7 @@ def test_bf16_conv_layers_match_bf16_oracle(rt, case):
         assert np.abs(g - r).max() <= 2e-4 * max(1.0, float(np.abs(r).max())), (case, float(np.abs(g - r).max()))
 
 
-@pytest.mark.parametrize("tile", range(17))
+@pytest.mark.parametrize("tile", range(20))
 def test_bf16_every_tile(rt, tile):
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights

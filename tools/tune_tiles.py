@@ -101,8 +101,14 @@ def main():
     if a.write:
         d = os.path.join(ROOT, "yolo-v3-tf2_amd", "tuning")
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, a.write), "w") as f:
-            json.dump({"batch": B, "image_size": S, "tiles": winners}, f, indent=1, sort_keys=True)
+        path = os.path.join(d, a.write)
+        doc = {"batch": B, "image_size": S, "tiles": winners}
+        if os.path.exists(path):     # keep the keys other tools own (lanes: tools/lanes_sweep.py)
+            with open(path) as f:
+                old = json.load(f)
+            doc.update({k: v for k, v in old.items() if k not in doc})
+        with open(path, "w") as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

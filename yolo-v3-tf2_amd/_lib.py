@@ -46,7 +46,8 @@ TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 3
 TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
               (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64),
               (128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (64, 128, 4, 64), (128, 256, 8, 64),  # 8..13: LDS-DMA loads
-              (256, 256, 8, 64), (256, 128, 4, 64), (128, 256, 4, 64)]  # 14..16: LDS-DMA, bigger wave tiles
+              (256, 256, 8, 64), (256, 128, 4, 64), (128, 256, 4, 64),  # 14..16: LDS-DMA, bigger wave tiles
+              (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64)]  # 17..19: LDS-DMA, 16 waves
 TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if i >= 26 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
 PROBE_TILES = (20, 21, 22, 25)  # timing-only ablations, wrong results
 

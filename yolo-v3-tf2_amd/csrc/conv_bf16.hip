@@ -318,6 +318,7 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 64},
     {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {64, 128, 4, 64}, {128, 256, 8, 64},  // 8..13: LDS-DMA
     {256, 256, 8, 64}, {256, 128, 4, 64}, {128, 256, 4, 64},  // 14..16: LDS-DMA, 128x64 / 64x128 wave tiles
+    {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64},   // 17..19: LDS-DMA, 16 waves (64x64 / 64x32 / 32x64 wave tiles)
 };
 
 TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < BF16_TILE_COUNT) ? tile : 0]; }
@@ -373,6 +374,9 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
         case 14: return launch_tb<4, 2, 2, 4, 64, true>(a, out_f32, s);   // 256x256, 8 waves (128x64 wave tile), LDS-DMA
         case 15: return launch_tb<4, 2, 2, 2, 64, true>(a, out_f32, s);   // 256x128, 4 waves (128x64 wave tile), LDS-DMA
         case 16: return launch_tb<2, 4, 2, 2, 64, true>(a, out_f32, s);   // 128x256, 4 waves (64x128 wave tile), LDS-DMA
+        case 17: return launch_tb<2, 2, 4, 4, 64, true>(a, out_f32, s);   // 256x256, 16 waves, LDS-DMA
+        case 18: return launch_tb<2, 1, 4, 4, 64, true>(a, out_f32, s);   // 256x128, 16 waves, LDS-DMA
+        case 19: return launch_tb<1, 2, 4, 4, 64, true>(a, out_f32, s);   // 128x256, 16 waves, LDS-DMA
         default: return hipErrorInvalidValue;
     }
 }
