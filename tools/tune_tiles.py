@@ -44,6 +44,9 @@ def main():
     TL = _lib.TILES_X3 if x3 else _lib.TILES_BF16 if bf else TILES
     TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if (i >= 8 and not x3) else "") + ("s1" if (x3 and i in (9, 10, 11, 13, 14, 15)) else "") + ("i" if (x3 and 20 <= i < 26) else "") + ("p" if (x3 and i in (28, 29)) else "") + ("s3" if (x3 and i >= 30) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
     tiles = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else list(range(len(TL)))
+    if a.tiles == "all":   # timing-only probe tiles (wrong results) must be asked for by id; never with --write
+        probes = _lib.PROBE_TILES_X2 if x2 else () if bf else _lib.PROBE_TILES
+        tiles = [t for t in tiles if t not in probes]
     if x2:
         tiles = [t for t in tiles if t in _lib.TILES_X2_BUILT + _lib.PROBE_TILES_X2]
     elif x3:
