@@ -115,6 +115,11 @@ y3_status y3_net_set_tile_x2(y3_net *net, int conv_slot, int tile);   /* same ti
  * (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
 y3_status y3_net_set_lanes(y3_net *net, int lanes);
 y3_status y3_net_keep_activations(y3_net *net, int keep);
+/* Before y3_net_plan: run the first n_convs convs chunk_images images at a time, then the rest of the network on the
+ * whole batch.  The first layers' activations are the largest tensors of the network (1.4 GB for 64 images at 416x416);
+ * in chunks they are still in the Infinity Cache when the next conv reads them.  Results are unchanged (images are
+ * independent).  0, 0 switches it off. */
+y3_status y3_net_set_early_chunk(y3_net *net, int n_convs, int chunk_images);
 
 /* Allocate the activation arena for batches up to `max_batch` of image_size x image_size inputs
  * and select the conv arithmetic type (Y3_DTYPE_*).  May be called again to re-plan.

@@ -444,6 +444,29 @@ def test_forward_lanes_bit_identical_other_modes(rt, program, weights, mode):
             assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("mode", ["f32", "f32x2", "bf16"])
+def test_early_chunk_bit_identical(rt, program, weights, mode):
+    """y3_net_set_early_chunk: the first convs run a few images at a time, alone and together with lanes -- same bits."""
+    from yolo_v3_tf2_amd import _lib
+    dt = {"f32": _lib.Y3_DTYPE_F32, "f32x2": _lib.Y3_DTYPE_F32X2, "bf16": _lib.Y3_DTYPE_BF16}[mode]
+    x = _cuda(np.random.default_rng(16).random((7, 96, 96, 3), dtype=np.float32))
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(7, 96, dt)
+    net.set_lanes(1)
+    a = [g.clone() for g in net.forward(x)]
+    for n_convs, chunk, lanes in ((9, 2, 1), (4, 3, 1), (9, 2, 2), (26, 1, 3), (9, 16, 1)):
+        net.set_early_chunk(n_convs, chunk)
+        net.plan(7, 96, dt)
+        net.set_lanes(lanes)
+        b = net.forward(x)
+        torch.cuda.synchronize()
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), (n_convs, chunk, lanes)
+    with pytest.raises(rt.Y3Error):
+        net.set_early_chunk(75, 2)
+
+
 def test_full_size_batch_properties(rt, program, weights, anchors):
     """BASELINE size (batch 64, 416x416) through size-independent properties: (1) determinism, (2) batch
     independence -- image i of the 64-batch equals the same image run alone, bit for bit (the per-pixel K order does

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--force", type=str, default="", help="comma list of tile ids to force on every conv they fit (one run each)")
+    ap.add_argument("--early", type=str, default="", help="n_convs:chunk pairs for y3_net_set_early_chunk, e.g. 9:4,9:8,4:4")
+    ap.add_argument("--lanes", type=str, default="1,2,3,4")
     a = ap.parse_args()
     dt = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3, "f32x2": _lib.Y3_DTYPE_F32X2}[a.dtype]
     p = load_program(os.path.join(ROOT, "config/models/yolov3/model.yaml"), 80)
@@ -32,7 +34,7 @@ def main():
     setter = {"f32": net.set_tile, "bf16": net.set_tile_bf16, "f32x3": net.set_tile_x3, "f32x2": net.set_tile_x2}[a.dtype]
 
     def measure(label):
-        for lanes in (1, 2, 3, 4):
+        for lanes in [int(v) for v in a.lanes.split(",")]:
             net.set_lanes(lanes)
             for _ in range(3):
                 net.forward(x)
@@ -48,6 +50,12 @@ def main():
 
     net.plan(a.batch, a.image_size, dt)
     measure("tuning table")
+    for pair in [v for v in a.early.split(",") if v]:
+        n_convs, chunk = (int(v) for v in pair.split(":"))
+        net.set_early_chunk(n_convs, chunk)
+        net.plan(a.batch, a.image_size, dt)
+        measure(f"early {n_convs} convs x {chunk} img")
+    net.set_early_chunk(0, 0)
     for t in [int(v) for v in a.force.split(",") if v]:
         net.plan(a.batch, a.image_size, dt)     # resets to the table
         for slot, o in enumerate(net.conv_ops):

@@ -86,6 +86,7 @@ SYMBOLS = {
     "y3_net_set_tile_bf16": (_i, [_vp, _i, _i]),
     "y3_net_set_tile_x3": (_i, [_vp, _i, _i]),
     "y3_net_set_tile_x2": (_i, [_vp, _i, _i]),
+    "y3_net_set_early_chunk": (_i, [_vp, _i, _i]),
     "y3_net_keep_activations": (_i, [_vp, _i]),
     "y3_net_set_lanes": (_i, [_vp, _i]),
     "y3_net_plan": (_i, [_vp, _i, _i, _i]),

@@ -79,6 +79,10 @@ struct y3_net {
     int max_batch = 0, image_size = 0, dtype = Y3_DTYPE_F32;
     int keep_all = 0;              // 1: no buffer reuse, every intermediate stays readable after a forward
     int lanes = 1;                 // sub-batches run concurrently on forked streams (y3_net_set_lanes)
+    int early_convs = 0;           // y3_net_set_early_chunk: the first early_convs convs run early_chunk images at a time
+    int early_chunk = 0;
+    int early_ops = 0;             // (at plan time) number of leading ops that form the chunked segment
+    std::vector<char> dense;       // tensor written by the chunked segment: own block, image i at i * image_bytes
     int cur_batch = 1;             // batch of the forward being enqueued
     hipEvent_t fork_ev = nullptr;
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -483,6 +487,15 @@ y3_status y3_net_set_lanes(y3_net *net, int lanes)
     return Y3_OK;
 }
 
+y3_status y3_net_set_early_chunk(y3_net *net, int n_convs, int chunk_images)
+{
+    if (!net || n_convs < 0 || chunk_images < 0) return fail(Y3_ERR_INVALID, "y3_net_set_early_chunk: bad argument");
+    if (n_convs >= (int)net->convs.size()) return fail(Y3_ERR_INVALID, "y3_net_set_early_chunk: n_convs must leave at least one conv for the full batch");
+    net->early_convs = (chunk_images > 0) ? n_convs : 0;
+    net->early_chunk = (n_convs > 0) ? chunk_images : 0;
+    return Y3_OK;
+}
+
 y3_status y3_net_keep_activations(y3_net *net, int keep)
 {
     if (!net) return fail(Y3_ERR_INVALID, "y3_net_keep_activations: null net");
@@ -520,6 +533,19 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
             touch(a.src0, i); touch(a.src1, i); touch(a.dst, i);
         }
     }
+    // chunked leading segment: every op before the (early_convs)-th conv; tensors it writes get blocks of their own,
+    // laid out densely by image, because they are rewritten chunk after chunk while earlier chunks' results are still live
+    net->early_ops = 0;
+    if (net->early_convs > 0 && net->early_chunk > 0) {
+        int seen = 0;
+        for (int i = 0; i < (int)net->ops.size(); ++i) {
+            if (net->ops[i].kind == 0 && seen++ == net->early_convs) break;
+            net->early_ops = i + 1;
+        }
+        if (net->early_ops >= (int)net->ops.size()) net->early_ops = 0;
+    }
+    net->dense.assign(nt, 0);
+    for (int t = 0; t < nt; ++t) net->dense[t] = (first[t] >= 0 && first[t] < net->early_ops) ? 1 : 0;
     for (int t = 0; t < nt; ++t) {
         const int s = image_size / net->tensors[t].div;
         net->tbytes[t] = (size_t)max_batch * s * s * net->tensors[t].channels * (dtype == Y3_DTYPE_BF16 ? 2 : dtype == Y3_DTYPE_F32X3 ? 6 : 4);   // two fp16 planes: 4 bytes as well
@@ -536,9 +562,9 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
     }
     std::sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
     for (int t : order) {
-        const int until = net->keep_all ? (int)net->ops.size() + 1 : last[t];
+        const int until = (net->keep_all || net->dense[t]) ? (int)net->ops.size() + 1 : last[t];
         int pick = -1;
-        for (int k = 0; k < (int)pool.size(); ++k)
+        for (int k = 0; k < (int)pool.size() && !net->dense[t]; ++k)
             if (pool[k].free_at < first[t] && pool[k].bytes >= net->tbytes[t] &&
                 (pick < 0 || pool[k].bytes < pool[pick].bytes))
                 pick = k;
@@ -572,9 +598,11 @@ double y3_net_flops_per_image(const y3_net *net)
 }
 
 // Enqueue the whole op list for images [b0, b0+nb) of the batch on stream s (tensor pointers offset by b0 images).
+// op_begin/op_end select a segment of the op list (-1: to the end).
 static y3_status run_slice(y3_net *net, const float *images, float *const grids[3], int b0, int nb, hipStream_t s,
-                           float *ms_out, int n_ms, int lane = 0, int lanes = 1)
+                           float *ms_out, int n_ms, int lane = 0, int lanes = 1, int op_begin = 0, int op_end = -1)
 {
+    if (op_end < 0) op_end = (int)net->ops.size();
     auto img_elems = [&](int t) -> size_t {
         const int sp = spatial(net, t);
         return (size_t)sp * sp * net->tensors[t].channels;
@@ -602,6 +630,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
         // own 1/lanes region of the block so that concurrent sub-batches never alias
         char *blk = static_cast<char *>(net->tdev[t]);
         if (!blk) return nullptr;
+        if (net->dense[t]) return blk + (size_t)b0 * img_elems(t) * esz(t);
         // lane regions start at the lane's first image (scaled to the block size), 256-B aligned; blocks carry 4 KiB of slack
         const size_t off = ((size_t)((double)net->tblock[t] * b0 / net->cur_batch) + 255) & ~(size_t)255;
         (void)lanes;
@@ -613,7 +642,8 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
     }
-    for (const Op &o : net->ops) {
+    for (int oi = op_begin; oi < op_end; ++oi) {
+        const Op &o = net->ops[oi];
         if (o.kind == 0) {
             ConvSlot &c = net->convs[o.index];
             const y3_conv_desc &d = c.d;
@@ -730,7 +760,20 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
     net->cur_batch = batch;
     int lanes = (ms_out || net->lanes < 2) ? 1 : net->lanes;
     while (lanes > 1 && batch / lanes < 1) --lanes;
-    if (lanes == 1) return run_slice(net, images, grids, 0, batch, s, ms_out, n_ms);
+    // leading segment in chunks small enough for their activations to stay in the 256 MB Infinity Cache between the
+    // conv that writes them and the one that reads them, then the rest of the op list on the whole (sub-)batch
+    const int k_early = ms_out ? 0 : net->early_ops;
+    auto run_lane = [&](int b0, int nb, hipStream_t st, int lane, int nl) -> y3_status {
+        if (k_early > 0) {
+            for (int c0 = 0; c0 < nb; c0 += net->early_chunk) {
+                const int cn = nb - c0 < net->early_chunk ? nb - c0 : net->early_chunk;
+                y3_status r = run_slice(net, images, grids, b0 + c0, cn, st, nullptr, 0, lane, nl, 0, k_early);
+                if (r != Y3_OK) return r;
+            }
+        }
+        return run_slice(net, images, grids, b0, nb, st, ms_out, n_ms, lane, nl, k_early, -1);
+    };
+    if (lanes == 1) return run_lane(0, batch, s, 0, 1);
     HIP_TRY(hipSetDevice(net->device));
     if (!net->fork_ev) {
         HIP_TRY(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
@@ -747,7 +790,7 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
         const int nb = start[l + 1] - start[l];
         if (nb <= 0) continue;
         HIP_TRY(hipStreamWaitEvent(net->lane_stream[l], net->fork_ev, 0));
-        y3_status st = run_slice(net, images, grids, start[l], nb, net->lane_stream[l], nullptr, 0, l, lanes);
+        y3_status st = run_lane(start[l], nb, net->lane_stream[l], l, lanes);
         if (st != Y3_OK) return st;
         HIP_TRY(hipEventRecord(net->join_ev[l], net->lane_stream[l]));
         HIP_TRY(hipStreamWaitEvent(s, net->join_ev[l], 0));

@@ -101,6 +101,11 @@ class Net:
     def set_lanes(self, lanes: int):
         check(self.lib.y3_net_set_lanes(self._h, int(lanes)), "y3_net_set_lanes")
 
+    def set_early_chunk(self, n_convs: int, chunk_images: int):
+        """Before plan(): the first n_convs convs run chunk_images images at a time (their activations then stay in the
+        Infinity Cache between producer and consumer); 0, 0 switches it off."""
+        check(self.lib.y3_net_set_early_chunk(self._h, int(n_convs), int(chunk_images)), "y3_net_set_early_chunk")
+
     def set_tile(self, slot: int, tile: int):
         check(self.lib.y3_net_set_tile(self._h, slot, tile), "y3_net_set_tile")
 
