@@ -21,7 +21,7 @@ def build(force=False, verbose=False):
     deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".h", ".hip", ".cpp"))]
     deps.append(os.path.join(HERE, "..", "..", "include", "y3.h"))
     newest = max(os.path.getmtime(d) for d in deps)
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
@@ -29,7 +29,12 @@ def build(force=False, verbose=False):
             cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
+    if jobs:   # the template-heavy conv files take a minute or two each: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(len(jobs), (os.cpu_count() or 2) // 2))
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(subprocess.check_call, jobs))
     if force or not os.path.exists(OUT) or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
         if verbose:
