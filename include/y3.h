@@ -198,6 +198,17 @@ y3_status y3_pack_detections(const float *bboxes_dev, const int64_t *class_idx_d
                              int max_out, void *packed_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The whole path in one call: Model(inputs, nms_output).predict(batch) followed by the per-image gather
+ * (reference: inference.py:109-117, 125-128, 21-28) = y3_net_forward -> y3_yolo_decode_scores -> y3_nms_padded ->
+ * y3_pack_detections on net-owned scratch.  images_dev [batch,S,S,3] fp32; anchors_host [3][3][2];
+ * packed_dev [batch,max_boxes,7] 32-bit words {xmin,ymin,xmax,ymax,score,class(int32),index(int32)}, rows >= num_valid
+ * zeroed; num_valid_dev [batch] int32.  Everything is enqueued on `stream`.
+ * ---------------------------------------------------------------------------------------- */
+y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const float *anchors_host, int max_boxes,
+                        float iou_threshold, float score_threshold, void *packed_dev, int32_t *num_valid_dev,
+                        void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * TFRecord framing checksum (host): CRC-32C (Castagnoli) of a host buffer, unmasked.  The tfrecords input source
  * (reference: core/load_tfrecords.py:97-99, tf.data.TFRecordDataset) verifies it per record.
  * ---------------------------------------------------------------------------------------- */

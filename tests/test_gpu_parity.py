@@ -467,6 +467,27 @@ def test_early_chunk_bit_identical(rt, program, weights, mode):
         net.set_early_chunk(75, 2)
 
 
+def test_detect_single_call_equals_composed_pipeline(rt, program, weights, anchors):
+    """y3_net_detect (forward -> decode/score -> NMS -> pack on net-owned scratch) == the four calls made one by one."""
+    x = _cuda(np.random.default_rng(31).random((3, 128, 128, 3), dtype=np.float32))
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(3, 128)
+    grids = net.forward(x)
+    bb, cc, ss = rt.yolo_decode_scores(grids, anchors, 80)
+    sel, nv = rt.nms_padded(bb, ss, 100, 0.5, 0.05)
+    want = rt.pack_detections(bb, cc, ss, sel, nv)
+    for _ in range(2):     # second call reuses the scratch
+        packed, nv2 = net.detect(x, anchors, 100, 0.5, 0.05)
+        torch.cuda.synchronize()
+        assert torch.equal(nv2, nv) and torch.equal(packed, want) and int(nv.sum()) > 0
+    boxes, scores, classes, idx = rt.unpack_detections(packed)
+    n0 = int(nv[0])
+    assert torch.equal(idx[0, :n0], sel[0, :n0]) and torch.equal(boxes[0, :n0], bb[0][sel[0, :n0].long()])
+    with pytest.raises(rt.Y3Error):
+        net.detect(x, anchors, 0, 0.5, 0.05)
+
+
 def test_full_size_batch_properties(rt, program, weights, anchors):
     """BASELINE size (batch 64, 416x416) through size-independent properties: (1) determinism, (2) batch
     independence -- image i of the 64-batch equals the same image run alone, bit for bit (the per-pixel K order does

@@ -83,6 +83,9 @@ struct y3_net {
     int early_chunk = 0;
     int early_ops = 0;             // (at plan time) number of leading ops that form the chunked segment
     std::vector<char> dense;       // tensor written by the chunked segment: own block, image i at i * image_bytes
+    // y3_net_detect scratch (grids, decoded boxes / classes / scores, selected indices, NMS workspace), sized for det_batch
+    void *det_buf = nullptr;
+    size_t det_bytes = 0;
     int cur_batch = 1;             // batch of the forward being enqueued
     hipEvent_t fork_ev = nullptr;
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -99,6 +102,9 @@ int spatial(const y3_net *n, int t) { return n->image_size / n->tensors[t].div; 
 
 void free_plan(y3_net *n)
 {
+    if (n->det_buf) (void)hipFree(n->det_buf);
+    n->det_buf = nullptr;
+    n->det_bytes = 0;
     for (void *p : n->blocks) (void)hipFree(p);
     n->blocks.clear();
     n->tdev.assign(n->tensors.size(), nullptr);
@@ -949,6 +955,55 @@ y3_status y3_class_scores(const float *conf_dev, const float *probs_dev, int bat
 }
 
 // ------------------------------------------------------------------------------------------ nms
+// ------------------------------------------------------------------------------------------ whole pipeline
+y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const float *anchors_host, int max_boxes,
+                        float iou_threshold, float score_threshold, void *packed_dev, int32_t *num_valid_dev,
+                        void *stream)
+{
+    if (!net || !images_dev || !anchors_host || !packed_dev || !num_valid_dev || batch <= 0)
+        return fail(Y3_ERR_INVALID, "y3_net_detect: bad argument");
+    if (net->nclasses <= 0) return fail(Y3_ERR_STATE, "y3_net_detect: the net was created without detection heads (nclasses = 0)");
+    if (!net->image_size) return fail(Y3_ERR_STATE, "y3_net_detect: call y3_net_plan first");
+    if (batch > net->max_batch) return fail(Y3_ERR_INVALID, "y3_net_detect: batch %d > planned %d", batch, net->max_batch);
+    int32_t gs[3];
+    size_t gelems[3], n = 0;
+    const size_t per = (size_t)3 * (5 + net->nclasses);
+    for (int i = 0; i < 3; ++i) {
+        gs[i] = spatial(net, net->outputs[i]);
+        gelems[i] = (size_t)batch * gs[i] * gs[i] * per;
+        n += (size_t)3 * gs[i] * gs[i];
+    }
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_grid0 = 0, o_grid1 = o_grid0 + up(gelems[0] * 4), o_grid2 = o_grid1 + up(gelems[1] * 4);
+    const size_t o_box = o_grid2 + up(gelems[2] * 4), o_cls = o_box + up((size_t)batch * n * 16);
+    const size_t o_score = o_cls + up((size_t)batch * n * 8), o_sel = o_score + up((size_t)batch * n * 4);
+    const size_t o_ws = o_sel + up((size_t)batch * max_boxes * 4);
+    const size_t ws_bytes = y3::nms_workspace_bytes(batch, (int)n);
+    const size_t need = o_ws + ws_bytes;
+    HIP_TRY(hipSetDevice(net->device));
+    if (net->det_bytes < need) {
+        if (net->det_buf) (void)hipFree(net->det_buf);
+        net->det_buf = nullptr;
+        net->det_bytes = 0;
+        HIP_TRY(hipMalloc(&net->det_buf, need));
+        net->det_bytes = need;
+    }
+    char *b = static_cast<char *>(net->det_buf);
+    float *grids[3] = {reinterpret_cast<float *>(b + o_grid0), reinterpret_cast<float *>(b + o_grid1),
+                       reinterpret_cast<float *>(b + o_grid2)};
+    y3_status st = y3_net_forward(net, images_dev, batch, grids, stream);
+    if (st != Y3_OK) return st;
+    float *boxes = reinterpret_cast<float *>(b + o_box), *scores = reinterpret_cast<float *>(b + o_score);
+    int64_t *cls = reinterpret_cast<int64_t *>(b + o_cls);
+    int32_t *sel = reinterpret_cast<int32_t *>(b + o_sel);
+    st = y3_yolo_decode_scores(grids, gs, batch, net->nclasses, anchors_host, boxes, cls, scores, stream);
+    if (st != Y3_OK) return st;
+    st = y3_nms_padded(boxes, scores, batch, (int)n, max_boxes, iou_threshold, score_threshold, sel, num_valid_dev,
+                       b + o_ws, ws_bytes, stream);
+    if (st != Y3_OK) return st;
+    return y3_pack_detections(boxes, cls, scores, sel, num_valid_dev, batch, (int)n, max_boxes, packed_dev, stream);
+}
+
 size_t y3_nms_workspace_bytes(int batch, int n) { return (batch > 0 && n > 0) ? y3::nms_workspace_bytes(batch, n) : 0; }
 
 y3_status y3_nms_padded(const float *bboxes_dev, const float *scores_dev, int batch, int n, int max_output_size,

@@ -205,6 +205,22 @@ class Net:
               "y3_net_read_tensor")
         return out
 
+    def detect(self, images: torch.Tensor, anchors, max_boxes: int, iou_threshold: float, score_threshold: float):
+        """The whole path in one C call (y3_net_detect): -> (packed [B,max_boxes,7] int32 words, num_valid [B] int32);
+        `unpack_detections` splits the rows."""
+        _need_cuda(images)
+        if images.dtype != torch.float32 or images.dim() != 4 or images.shape[3] != 3:
+            raise Y3Error("images must be float32 [B,S,S,3]")
+        B, S = images.shape[0], images.shape[1]
+        if S != self.image_size or B > self.max_batch:
+            self.plan(max(B, self.max_batch), S)
+        a = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(3, 3, 2))
+        packed = torch.empty((B, int(max_boxes), 7), dtype=torch.int32, device=images.device)
+        nv = torch.empty((B,), dtype=torch.int32, device=images.device)
+        check(self.lib.y3_net_detect(self._h, _dev(images), B, _fptr(a), int(max_boxes), float(iou_threshold),
+                                     float(score_threshold), _dev(packed), _dev(nv), _lib.stream_ptr()), "y3_net_detect")
+        return packed, nv
+
     def flops_per_image(self) -> float:
         return float(self.lib.y3_net_flops_per_image(self._h))
 
