@@ -225,6 +225,23 @@ def test_x2_split_is_accurate_to_2_pow_minus_22(rt):
     assert ((back - x).abs()[~big] <= 2.0 ** -36).all()      # lo plane subnormal: absolute error <= 2^-25 * 2^-11
 
 
+def test_x2_rejects_weights_outside_fp16_range_only_in_that_mode(rt):
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    p = mini_program(64, [], [dict(filters=64, size=1), dict(filters=64, size=1), dict(filters=64, size=1)])
+    w = synthetic_weights(p, seed=1)
+    k = next(k for k in w if k.endswith(".w"))
+    w[k] = w[k].copy()
+    w[k].flat[0] = 1.0e6          # far outside fp16 after any BN scale
+    net = rt.Net(p)
+    net.load_weights(w)           # loading succeeds: the other modes can use these weights
+    net.plan(1, 8, _lib.Y3_DTYPE_F32)
+    net.forward(_cuda(np.zeros((1, 8, 8, 64), np.float32)))
+    with pytest.raises(rt.Y3Error, match="fp16 range"):
+        net.plan(1, 8, _lib.Y3_DTYPE_F32X2)
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 8, 9, 10, 12, 26, 27, 30, 31, 32, 33])
 def test_x2_every_tile(rt, tile):
     from tests.helpers import mini_program

@@ -50,6 +50,7 @@ struct ConvSlot {
     int cout_pad64 = 0;        // Cout rounded up to 64 (the three-plane kernel has no 32-wide N tile)
     void *wx3_dev = nullptr;   // packed [CoutPad64][3 planes][K] bf16 (hi, mid, lo of the fp32 weights)
     int tile_x2 = -1;
+    bool x2_ok = true;         // false: a BN-scaled weight is outside the fp16 range, the two-plane mode cannot be planned
     void *wx2_dev = nullptr;   // packed [CoutPad64][2 planes][K] fp16 (h, l' = (w - h) * 2^11 of the BN-scaled weights)
     float *w_dev = nullptr;    // packed [CoutPad][K] (or HWIO for the first layer)
     void *wbf_dev = nullptr;   // same, bf16 (not for the first layer)
@@ -414,11 +415,11 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
         HIP_TRY(hipMemcpy(c.wx3_dev, px.data(), px.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         // two fp16 planes of the BN-scaled weights: w = h + l' * 2^-11 (up to 2^-22 |w|); |w| must stay below 65504
         std::vector<unsigned short> p2((size_t)CP64 * 2 * K, 0);
+        c.x2_ok = true;
         for (int n = 0; n < d.cout; ++n)
             for (int k = 0; k < K; ++k) {
                 const float x = pk_scaled[(size_t)n * K + k];
-                if (!(fabsf(x) < 65504.0f))
-                    return fail(Y3_ERR_INVALID, "conv %d: BN-scaled weight %g is outside the fp16 range of the two-plane mode", slot, (double)x);
+                if (!(fabsf(x) < 65504.0f)) c.x2_ok = false;   // reported by y3_net_plan(Y3_DTYPE_F32X2); other modes are unaffected
                 const unsigned short h = f32_to_f16_rne(x);
                 p2[((size_t)n * 2 + 0) * K + k] = h;
                 p2[((size_t)n * 2 + 1) * K + k] = f32_to_f16_rne((x - f16_to_f32(h)) * 2048.0f);
@@ -516,6 +517,11 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
         return fail(Y3_ERR_INVALID, "y3_net_plan: unknown dtype %d", dtype);
     for (const y3_tensor_desc &t : net->tensors)
         if (t.div <= 0 || image_size % t.div) return fail(Y3_ERR_INVALID, "y3_net_plan: image_size %d not divisible by %d", image_size, t.div);
+    if (dtype == Y3_DTYPE_F32X2)
+        for (size_t i = 0; i < net->convs.size(); ++i)
+            if (net->convs[i].loaded && !net->convs[i].x2_ok)
+                return fail(Y3_ERR_INVALID, "y3_net_plan: conv %zu has a BN-scaled weight outside the fp16 range (|w| >= 65504); "
+                                            "the two-plane mode cannot represent it, use Y3_DTYPE_F32 or Y3_DTYPE_F32X3", i);
     HIP_TRY(hipSetDevice(net->device));
     free_plan(net);
     net->max_batch = max_batch;
@@ -758,6 +764,9 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
     if (batch > net->max_batch) return fail(Y3_ERR_INVALID, "y3_net_forward: batch %d > planned %d", batch, net->max_batch);
     for (size_t i = 0; i < net->convs.size(); ++i)
         if (!net->convs[i].loaded) return fail(Y3_ERR_STATE, "y3_net_forward: conv %zu has no weights", i);
+    if (net->dtype == Y3_DTYPE_F32X2)
+        for (size_t i = 0; i < net->convs.size(); ++i)
+            if (!net->convs[i].x2_ok) return fail(Y3_ERR_INVALID, "y3_net_forward: conv %zu has a weight outside the fp16 range of the two-plane mode", i);
     for (int i = 0; i < 3; ++i)
         if (!grids[i] || ((uintptr_t)grids[i] & 15)) return fail(Y3_ERR_INVALID, "y3_net_forward: grid %d null or not 16-byte aligned", i);
     if ((uintptr_t)images & 3) return fail(Y3_ERR_INVALID, "y3_net_forward: images not 4-byte aligned");
