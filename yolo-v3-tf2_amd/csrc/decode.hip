@@ -2,10 +2,12 @@
 //
 // Replaces reference core/yolo_decode_layer.py:4-36 (split, sigmoid x3, exp*anchor, meshgrid add,
 // divide, +-wh/2, concat, reshape, concat) and core/yolo_nms.py:18-24 (argmax, reduce_max, multiply).
-// HBM-bound: 4*(5+nc) bytes read per box.  A workgroup copies 128 boxes (contiguous 128*(5+nc)
-// floats of one scale) into LDS with 16-B coalesced loads, then each lane owns one box and walks
-// its 5+nc values from LDS (row stride 5+nc = 85 dwords is odd -> conflict-free ds_read_b32);
-// class probabilities are written back through LDS so that the [B,N,nc] store is coalesced.
+// HBM-bound: 4*(5+nc) bytes read per box.  A workgroup of 256 lanes copies 64 boxes (contiguous 64*(5+nc)
+// floats of one scale) into LDS with 16-B coalesced loads; four lanes then share one box: lane q takes field q of
+// (x, y, w, h) and the classes q, q+4, q+8, ... (a quarter of the sigmoids each), and the four partial
+// (first-maximum, index) pairs are merged with two lane exchanges.  22 KB of LDS per workgroup keeps 7 workgroups =
+// 28 waves per CU in flight, so the copy of one workgroup overlaps the sigmoids of the others.  Class probabilities are
+// written back through LDS so that the [B,N,nc] store is coalesced.
 // Arithmetic: sigmoid(x) = 1/(1+exp(-x)), true divisions, fp32, no contraction (-ffp-contract=off).
 #include "y3_kernels.h"
 
@@ -13,7 +15,9 @@ namespace y3 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int DEC_BOXES = 128;  // boxes per workgroup == threads per workgroup
+static constexpr int DEC_BOXES = 64;    // boxes per workgroup
+static constexpr int DEC_LANES = 4;     // lanes per box
+static constexpr int DEC_THREADS = DEC_BOXES * DEC_LANES;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -23,9 +27,9 @@ struct DecodeLaunch {
 };
 
 template <bool WRITE_PROBS, bool WRITE_SCORES>
-__global__ __launch_bounds__(DEC_BOXES) void decode_kernel(const DecodeLaunch L, float *__restrict__ bboxes,
-                                                           float *__restrict__ conf, float *__restrict__ probs,
-                                                           int64_t *__restrict__ cls, float *__restrict__ scores)
+__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeLaunch L, float *__restrict__ bboxes,
+                                                             float *__restrict__ conf, float *__restrict__ probs,
+                                                             int64_t *__restrict__ cls, float *__restrict__ scores)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int F = 5 + L.a.nc;
@@ -42,44 +46,66 @@ __global__ __launch_bounds__(DEC_BOXES) void decode_kernel(const DecodeLaunch L,
     const int tid = threadIdx.x;
     // coalesced copy (16 B per lane; box0*F*4 is a multiple of 16 because DEC_BOXES*4 is)
     const int nvec = nfl >> 2;
-    for (int i = tid; i < nvec; i += DEC_BOXES) reinterpret_cast<f32x4 *>(lds)[i] = reinterpret_cast<const f32x4 *>(src)[i];
-    for (int i = (nvec << 2) + tid; i < nfl; i += DEC_BOXES) lds[i] = src[i];
+    for (int i = tid; i < nvec; i += DEC_THREADS) reinterpret_cast<f32x4 *>(lds)[i] = reinterpret_cast<const f32x4 *>(src)[i];
+    for (int i = (nvec << 2) + tid; i < nfl; i += DEC_THREADS) lds[i] = src[i];
     __syncthreads();
 
-    long long out_row = 0;
-    if (tid < nbox) {
-        const long long gi = box0 + tid;
-        const int b = (int)(gi / per_img);
-        const int r = (int)(gi - (long long)b * per_img);
-        const int a = r % 3;
-        const int cell = r / 3;
-        const int row = cell / g, col = cell - row * g;
-        out_row = (long long)b * L.a.N + L.a.off[s] + r;
-        float *t = lds + tid * F;
-        // grid = meshgrid(range(W), range(H)): (...,0) = col, (...,1) = row; divisor cast([H,W]) (square grid)
-        const float x = (sigmoidf_(t[0]) + (float)col) / (float)g;
-        const float y = (sigmoidf_(t[1]) + (float)row) / (float)g;
-        const float w = expf(t[2]) * L.a.anchors[s][a][0];
-        const float h = expf(t[3]) * L.a.anchors[s][a][1];
+    const int j = tid >> 2, q = tid & 3;          // box within the workgroup, lane within the box
+    const bool live = j < nbox;
+    const int jj = live ? j : 0;
+    const long long gi = box0 + jj;
+    const int b = (int)(gi / per_img);
+    const int r = (int)(gi - (long long)b * per_img);
+    const int a = r % 3;
+    const int cell = r / 3;
+    const int row = cell / g, col = cell - row * g;
+    const long long out_row = (long long)b * L.a.N + L.a.off[s] + r;
+    float *t = lds + jj * F;
+    // grid = meshgrid(range(W), range(H)): (...,0) = col, (...,1) = row; divisor cast([H,W]) (square grid).
+    // lane 0: x, lane 1: y, lane 2: w, lane 3: h
+    float v;
+    if (q < 2)
+        v = (sigmoidf_(t[q]) + (float)(q == 0 ? col : row)) / (float)g;
+    else
+        v = expf(t[q]) * L.a.anchors[s][a][q - 2];
+    const int base = (tid & 63) & ~3;             // first lane of this box inside the wave
+    const float x = __shfl(v, base + 0), y = __shfl(v, base + 1), w = __shfl(v, base + 2), h = __shfl(v, base + 3);
+    float c = 0.0f;
+    if (q == 0) {
         f32x4 bb;
         bb[0] = x - w / 2;
         bb[1] = y - h / 2;
         bb[2] = x + w / 2;
         bb[3] = y + h / 2;
-        *reinterpret_cast<f32x4 *>(bboxes + out_row * 4) = bb;
-        const float c = sigmoidf_(t[4]);
-        if (conf) conf[out_row] = c;
-        float best = 0.0f;
-        int besti = 0;
-        for (int k = 0; k < L.a.nc; ++k) {
-            const float pk = sigmoidf_(t[5 + k]);
-            if (WRITE_PROBS) t[5 + k] = pk;
-            if (k == 0 || pk > best) {  // first maximum wins, like tf.argmax
-                best = pk;
-                besti = k;
+        c = sigmoidf_(t[4]);
+        if (live) {
+            *reinterpret_cast<f32x4 *>(bboxes + out_row * 4) = bb;
+            if (conf) conf[out_row] = c;
+        }
+    }
+    // classes q, q+4, ...: first maximum of the lane's own subsequence, then of the four lanes (ties -> lowest index,
+    // like tf.argmax over the whole row)
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = q; k < L.a.nc; k += DEC_LANES) {
+        const float pk = sigmoidf_(t[5 + k]);
+        if (WRITE_PROBS && live) t[5 + k] = pk;
+        if (k == q || pk > best) {
+            best = pk;
+            besti = k;
+        }
+    }
+    if (WRITE_SCORES) {
+#pragma unroll
+        for (int m = 1; m < DEC_LANES; m <<= 1) {
+            const float ob = __shfl_xor(best, m);
+            const int oi = __shfl_xor(besti, m);
+            if (ob > best || (ob == best && oi < besti)) {
+                best = ob;
+                besti = oi;
             }
         }
-        if (WRITE_SCORES) {
+        if (q == 0 && live) {
             cls[out_row] = (int64_t)besti;
             scores[out_row] = c * best;
         }
@@ -89,13 +115,13 @@ __global__ __launch_bounds__(DEC_BOXES) void decode_kernel(const DecodeLaunch L,
         // the block's boxes may straddle images; rows of one image are contiguous in probs, so resolve per box
         const int nc = L.a.nc;
         const int nout = nbox * nc;
-        for (int i = tid; i < nout; i += DEC_BOXES) {
-            const int j = i / nc, k = i - j * nc;
-            const long long gi = box0 + j;
-            const int b = (int)(gi / per_img);
-            const int r = (int)(gi - (long long)b * per_img);
-            const long long orow = (long long)b * L.a.N + L.a.off[s] + r;
-            probs[orow * nc + k] = lds[j * F + 5 + k];
+        for (int i = tid; i < nout; i += DEC_THREADS) {
+            const int jb = i / nc, k = i - jb * nc;
+            const long long gj = box0 + jb;
+            const int bj = (int)(gj / per_img);
+            const int rj = (int)(gj - (long long)bj * per_img);
+            const long long orow = (long long)bj * L.a.N + L.a.off[s] + rj;
+            probs[orow * nc + k] = lds[jb * F + 5 + k];
         }
     }
 }
@@ -114,7 +140,7 @@ hipError_t launch_decode(const DecodeArgs &a, float *bboxes, float *conf, float 
     L.blk_start[3] = acc;
     const size_t lds = (size_t)DEC_BOXES * (5 + a.nc) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    dim3 grid(acc), block(DEC_BOXES);
+    dim3 grid(acc), block(DEC_THREADS);
     const bool wp = probs != nullptr, wsc = scores != nullptr;
     auto go = [&](auto k) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
