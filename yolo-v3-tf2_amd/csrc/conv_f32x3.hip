@@ -122,7 +122,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    // ILV == 4 (timing probe, wrong results): two workgroups per output tile, each running half of the K loop
+    const int nwg = ILV == 4 ? (int)gridDim.x >> 1 : (int)gridDim.x, bid = ILV == 4 ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int tilesN = p.CoutPad / BN;
@@ -298,7 +299,15 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.0f;
 
-    const int KT = p.K / BK;
+    int KT = p.K / BK;
+    if (ILV == 4) {
+        const int half = blockIdx.x & 1, k0 = half ? KT / 2 : 0;
+        kglob = k0 * BK;
+        tap = kglob / p.Cin;
+        c0 = kglob - tap * p.Cin;
+        if (!CONCAT) set_tap();
+        KT = half ? KT - KT / 2 : KT / 2;     // k tiles of this half; the loop below counts from 0
+    }
     fetch_dma(0);
     if (STAGES == 3 && KT > 1) {
         fetch_dma(1);
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = (STAGES == 3) ? cur3 : (STAGES == 2) ? (kt & 1) : 0;
         const bool more = kt + 1 < KT;
-        if (STAGES == 2 && (!ILV || ILV == 3) && more) fetch_dma(cur ^ 1);
+        if (STAGES == 2 && (!ILV || ILV >= 3) && more) fetch_dma(cur ^ 1);
         if (STAGES == 3 && kt + 2 < KT) fetch_dma(cur3 == 0 ? 2 : cur3 - 1);   // stage of tile kt-1, free since the last barrier
         constexpr int NP = NPL * (AP + BP);             // DMA instructions per tile
         constexpr int NG = (BK / 16) * TM * TN;         // MFMA groups (MPG MFMAs each) per tile
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (ILV && ILV != 3 && STAGES == 2) {
+                    if (ILV && ILV < 3 && STAGES == 2) {
                         // issued on the last tile too (branch-free): it lands in the idle stage, and every address
                         // is range-checked by its buffer descriptor
 #pragma unroll
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
-        if (ILV && ILV != 3 && STAGES == 2) dma_advance();
+        if (ILV && ILV < 3 && STAGES == 2) dma_advance();
         if (STAGES == 3) {
             if (kt + 2 < KT)
                 wait_all_but_newest_tile();
@@ -490,6 +499,7 @@ static const TileInfo kTilesX3[X3_TILE_COUNT] = {
     {256, 128, 16, 32}, {128, 256, 16, 32},                                       // 26..27: 16 waves, 64x32 wave tiles
     {256, 128, 16, 32}, {128, 128, 8, 32},                                        // 28..29: two-plane timing probes (A fetched for tap 0 only)
     {128, 128, 8, 32}, {256, 128, 16, 32}, {256, 128, 8, 32}, {128, 256, 16, 32},  // 30..33: three LDS stages
+    {256, 128, 16, 32}, {128, 128, 8, 32}, {256, 128, 8, 32},                      // 34..36: two-plane timing probes (K loop split over two workgroups)
 };
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
@@ -511,7 +521,7 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN * (ILV == 4 ? 2 : 1)), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }
 
@@ -595,6 +605,9 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 31: return launch_tp<2, 2, 1, 4, 4, 32, 3>(a, out_f32, s);      // 256x128 w16, three stages
         case 32: return launch_tp<2, 2, 2, 4, 2, 32, 3>(a, out_f32, s);      // 256x128 w8, three stages
         case 33: return launch_tp<2, 2, 1, 2, 8, 32, 3>(a, out_f32, s);      // 128x256 w16, three stages
+        case 34: return launch_tp<2, 2, 1, 4, 4, 32, 2, 4>(a, out_f32, s);   // probe: 256x128 w16, split K
+        case 35: return launch_tp<2, 2, 1, 2, 4, 32, 2, 4>(a, out_f32, s);   // probe: 128x128 w8, split K
+        case 36: return launch_tp<2, 2, 2, 4, 2, 32, 2, 4>(a, out_f32, s);   // probe: 256x128 w8, split K
         default: return hipErrorInvalidValue;
     }
 }
@@ -604,7 +617,7 @@ bool conv_x3_tile_built(int tile) { return (tile >= 0 && tile <= 27) || tile == 
 bool conv_x2_tile_built(int tile)
 {
     switch (tile) {
-        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: return true;
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: return true;
         default: return false;
     }
 }
