@@ -107,6 +107,7 @@ int main()
     for (int wps = 2; wps <= 4; wps *= 2) {
         int blocks = 256 * wps;
         printf("-- %d wave(s) per SIMD\n", wps);
+        run<1, false, false, false, 0>("mfma only, 1 acc (every MFMA waits for the one before)", blocks, out, in, it);
         run<2, false, false, false, 0>("mfma only, 2 acc", blocks, out, in, it);
         run<2, true, true, false, 0>("+ ds_read + barriers", blocks, out, in, it);
         run<2, true, true, true, 0>("+ ds_read + barriers + 6 ds_write_b128", blocks, out, in, it);

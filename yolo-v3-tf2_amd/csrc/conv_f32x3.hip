@@ -93,9 +93,14 @@ __device__ __forceinline__ void join_planes(const u32x4 (&q)[NPL], int k, float 
     }
 }
 
-// ILV: the LDS-DMA instructions of the next K tile are issued one or two at a time between the MFMA groups of the
-// current tile instead of as one burst (a burst costs every wave ~100 issue cycles per instruction at the same moment).
-template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int ILV = 0>
+// VAR: schedule variants and timing probes of the K loop (one kernel body, so that they stay comparable):
+//   V_BURST      the LDS-DMA instructions of the next K tile are issued together at the top of the iteration (default)
+//   V_ILV        ... issued one or two at a time between the MFMA groups of the current tile (measured: no gain)
+//   V_ILV_PINNED ... and pinned there with sched_group_barrier (no gain)
+//   V_PROBE_A1   timing only, WRONG RESULTS: activations fetched for the first tap only
+//   V_PROBE_SK   timing only, WRONG RESULTS: two workgroups per output tile, each running half of the K loop
+enum { V_BURST = 0, V_ILV = 1, V_ILV_PINNED = 2, V_PROBE_A1 = 3, V_PROBE_SK = 4 };
+template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int VAR = V_BURST>
 __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p)
 {
     static_assert(NPL == 2 || NPL == 3, "two fp16 planes or three bf16 planes");
@@ -122,8 +127,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
 
-    // ILV == 4 (timing probe, wrong results): two workgroups per output tile, each running half of the K loop
-    const int nwg = ILV == 4 ? (int)gridDim.x >> 1 : (int)gridDim.x, bid = ILV == 4 ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
+    constexpr bool ILV = VAR == V_ILV || VAR == V_ILV_PINNED;
+    const int nwg = VAR == V_PROBE_SK ? (int)gridDim.x >> 1 : (int)gridDim.x;
+    const int bid = VAR == V_PROBE_SK ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int tilesN = p.CoutPad / BN;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
         for (int pl = 0; pl < NPL; ++pl) {
             unsigned char *sa = smem + buf * STAGE_B + pl * PLANE_B + wave * RPI * ROWB;
             unsigned char *sb = sa + BM * ROWB;
-            if (ILV == 3 && tap != 0) {
+            if (VAR == V_PROBE_A1 && tap != 0) {
                 // timing probe (results are wrong): activations fetched for the first tap only -- what would a 3x3
                 // conv gain if its A operand came from an LDS-resident halo patch instead of one L2 read per tap?
             } else if (CONCAT && c0 >= p.C0) {
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                 for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.0f;
 
     int KT = p.K / BK;
-    if (ILV == 4) {
+    if (VAR == V_PROBE_SK) {
         const int half = blockIdx.x & 1, k0 = half ? KT / 2 : 0;
         kglob = k0 * BK;
         tap = kglob / p.Cin;
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = (STAGES == 3) ? cur3 : (STAGES == 2) ? (kt & 1) : 0;
         const bool more = kt + 1 < KT;
-        if (STAGES == 2 && (!ILV || ILV >= 3) && more) fetch_dma(cur ^ 1);
+        if (STAGES == 2 && !ILV && more) fetch_dma(cur ^ 1);
         if (STAGES == 3 && kt + 2 < KT) fetch_dma(cur3 == 0 ? 2 : cur3 - 1);   // stage of tile kt-1, free since the last barrier
         constexpr int NP = NPL * (AP + BP);             // DMA instructions per tile
         constexpr int NG = (BK / 16) * TM * TN;         // MFMA groups (MPG MFMAs each) per tile
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (ILV && ILV < 3 && STAGES == 2) {
+                    if (ILV && STAGES == 2) {
                         // issued on the last tile too (branch-free): it lands in the idle stage, and every address
                         // is range-checked by its buffer descriptor
 #pragma unroll
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                 }
         }
         (void)grp;
-        if (ILV == 2 && STAGES == 2) {
+        if (VAR == V_ILV_PINNED && STAGES == 2) {
             // pin the issue order: a few MFMAs, then one DMA instruction, repeated
 #pragma unroll
             for (int g = 0; g < NP; ++g) {
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
-        if (ILV && ILV < 3 && STAGES == 2) dma_advance();
+        if (ILV && STAGES == 2) dma_advance();
         if (STAGES == 3) {
             if (kt + 2 < KT)
                 wait_all_but_newest_tile();
@@ -504,7 +510,7 @@ static const TileInfo kTilesX3[X3_TILE_COUNT] = {
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
 
-template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int ILV = 0>
+template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int VAR = V_BURST>
 static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
@@ -513,7 +519,7 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
     const size_t ctile = (size_t)WR * 32 * (BN + 4) * sizeof(float);
     const size_t lds = stages > ctile ? stages : ctile;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = conv_f32x3_mfma<NPL, TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES, ILV>;
+    auto k = conv_f32x3_mfma<NPL, TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -521,24 +527,24 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, dim3(tilesM * tilesN * (ILV == 4 ? 2 : 1)), dim3(64 * WR * WC), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN * (VAR == V_PROBE_SK ? 2 : 1)), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }
 
-template <int NPL, int TM, int TN, int WR, int WC, int BK, int STAGES = 2, int ILV = 0>
+template <int NPL, int TM, int TN, int WR, int WC, int BK, int STAGES = 2, int VAR = V_BURST>
 static hipError_t launch_tp(const ConvArgs &a, bool out_f32, hipStream_t s)
 {
     if (a.src1)
-        return out_f32 ? launch_kx<NPL, TM, TN, WR, WC, BK, true, true, STAGES, ILV>(a, s)
-                       : launch_kx<NPL, TM, TN, WR, WC, BK, true, false, STAGES, ILV>(a, s);
-    return out_f32 ? launch_kx<NPL, TM, TN, WR, WC, BK, false, true, STAGES, ILV>(a, s)
-                   : launch_kx<NPL, TM, TN, WR, WC, BK, false, false, STAGES, ILV>(a, s);
+        return out_f32 ? launch_kx<NPL, TM, TN, WR, WC, BK, true, true, STAGES, VAR>(a, s)
+                       : launch_kx<NPL, TM, TN, WR, WC, BK, true, false, STAGES, VAR>(a, s);
+    return out_f32 ? launch_kx<NPL, TM, TN, WR, WC, BK, false, true, STAGES, VAR>(a, s)
+                   : launch_kx<NPL, TM, TN, WR, WC, BK, false, false, STAGES, VAR>(a, s);
 }
 
-template <int TM, int TN, int WR, int WC, int BK, int STAGES = 2, int ILV = 0>
+template <int TM, int TN, int WR, int WC, int BK, int STAGES = 2, int VAR = V_BURST>
 static hipError_t launch_tx(const ConvArgs &a, bool out_f32, hipStream_t s)
 {
-    return launch_tp<3, TM, TN, WR, WC, BK, STAGES, ILV>(a, out_f32, s);
+    return launch_tp<3, TM, TN, WR, WC, BK, STAGES, VAR>(a, out_f32, s);
 }
 
 hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
@@ -567,12 +573,12 @@ hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 17: return launch_tx<2, 2, 4, 2, 16>(a, out_f32, s);      // 256x128 w8, BK 16 (2 workgroups / CU)
         case 18: return launch_tx<2, 2, 2, 4, 16>(a, out_f32, s);      // 128x256 w8, BK 16
         case 19: return launch_tx<2, 2, 2, 2, 16>(a, out_f32, s);      // 128x128 w4, BK 16 (3 workgroups / CU)
-        case 20: return launch_tx<2, 2, 4, 2, 32, 2, 1>(a, out_f32, s);   // 256x128 w8, DMA issue interleaved with MFMA groups
-        case 21: return launch_tx<2, 2, 2, 4, 32, 2, 1>(a, out_f32, s);   // 128x256 w8, interleaved
-        case 22: return launch_tx<2, 2, 2, 2, 32, 2, 1>(a, out_f32, s);   // 128x128 w4, interleaved
-        case 23: return launch_tx<2, 1, 2, 4, 32, 2, 1>(a, out_f32, s);   // 128x128 w8, interleaved
-        case 24: return launch_tx<2, 2, 4, 2, 32, 2, 2>(a, out_f32, s);   // 256x128 w8, interleaved + pinned issue order
-        case 25: return launch_tx<2, 2, 2, 4, 32, 2, 2>(a, out_f32, s);   // 128x256 w8, interleaved + pinned
+        case 20: return launch_tx<2, 2, 4, 2, 32, 2, V_ILV>(a, out_f32, s);   // 256x128 w8, DMA issue interleaved with MFMA groups
+        case 21: return launch_tx<2, 2, 2, 4, 32, 2, V_ILV>(a, out_f32, s);   // 128x256 w8, interleaved
+        case 22: return launch_tx<2, 2, 2, 2, 32, 2, V_ILV>(a, out_f32, s);   // 128x128 w4, interleaved
+        case 23: return launch_tx<2, 1, 2, 4, 32, 2, V_ILV>(a, out_f32, s);   // 128x128 w8, interleaved
+        case 24: return launch_tx<2, 2, 4, 2, 32, 2, V_ILV_PINNED>(a, out_f32, s);   // 256x128 w8, interleaved + pinned issue order
+        case 25: return launch_tx<2, 2, 2, 4, 32, 2, V_ILV_PINNED>(a, out_f32, s);   // 128x256 w8, interleaved + pinned
         case 26: return launch_tx<2, 1, 4, 4, 32>(a, out_f32, s);         // 256x128 w16 (64x32 wave tile)
         case 27: return launch_tx<2, 1, 2, 8, 32>(a, out_f32, s);         // 128x256 w16
         case 30: return launch_tx<2, 1, 2, 4, 32, 3>(a, out_f32, s);      // 128x128 w8, three stages
@@ -599,15 +605,15 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 12: return launch_tp<2, 2, 1, 2, 4, 32>(a, out_f32, s);      // 128x128 w8
         case 26: return launch_tp<2, 2, 1, 4, 4, 32>(a, out_f32, s);      // 256x128 w16
         case 27: return launch_tp<2, 2, 1, 2, 8, 32>(a, out_f32, s);      // 128x256 w16
-        case 28: return launch_tp<2, 2, 1, 4, 4, 32, 2, 3>(a, out_f32, s);   // probe: 256x128 w16, A for tap 0 only
-        case 29: return launch_tp<2, 2, 1, 2, 4, 32, 2, 3>(a, out_f32, s);   // probe: 128x128 w8, A for tap 0 only
+        case 28: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_A1>(a, out_f32, s);   // probe: 256x128 w16, A for tap 0 only
+        case 29: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_A1>(a, out_f32, s);   // probe: 128x128 w8, A for tap 0 only
         case 30: return launch_tp<2, 2, 1, 2, 4, 32, 3>(a, out_f32, s);      // 128x128 w8, three stages
         case 31: return launch_tp<2, 2, 1, 4, 4, 32, 3>(a, out_f32, s);      // 256x128 w16, three stages
         case 32: return launch_tp<2, 2, 2, 4, 2, 32, 3>(a, out_f32, s);      // 256x128 w8, three stages
         case 33: return launch_tp<2, 2, 1, 2, 8, 32, 3>(a, out_f32, s);      // 128x256 w16, three stages
-        case 34: return launch_tp<2, 2, 1, 4, 4, 32, 2, 4>(a, out_f32, s);   // probe: 256x128 w16, split K
-        case 35: return launch_tp<2, 2, 1, 2, 4, 32, 2, 4>(a, out_f32, s);   // probe: 128x128 w8, split K
-        case 36: return launch_tp<2, 2, 2, 4, 2, 32, 2, 4>(a, out_f32, s);   // probe: 256x128 w8, split K
+        case 34: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 256x128 w16, split K
+        case 35: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 128x128 w8, split K
+        case 36: return launch_tp<2, 2, 2, 4, 2, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 256x128 w8, split K
         default: return hipErrorInvalidValue;
     }
 }
