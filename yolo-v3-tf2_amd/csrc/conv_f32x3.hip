@@ -99,7 +99,9 @@ __device__ __forceinline__ void join_planes(const u32x4 (&q)[NPL], int k, float 
 //   V_ILV_PINNED ... and pinned there with sched_group_barrier (no gain)
 //   V_PROBE_A1   timing only, WRONG RESULTS: activations fetched for the first tap only
 //   V_PROBE_SK   timing only, WRONG RESULTS: two workgroups per output tile, each running half of the K loop
-enum { V_BURST = 0, V_ILV = 1, V_ILV_PINNED = 2, V_PROBE_A1 = 3, V_PROBE_SK = 4 };
+//   V_PROBE_NOLD timing only, WRONG RESULTS: no operand fetches after the first K tile (LDS reads + MFMAs + barriers only)
+//   V_PROBE_LDONLY timing only, WRONG RESULTS: operand fetches and barriers only, no LDS reads, no MFMAs
+enum { V_BURST = 0, V_ILV = 1, V_ILV_PINNED = 2, V_PROBE_A1 = 3, V_PROBE_SK = 4, V_PROBE_NOLD = 5, V_PROBE_LDONLY = 6 };
 template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int VAR = V_BURST>
 __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p)
 {
@@ -334,14 +336,14 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = (STAGES == 3) ? cur3 : (STAGES == 2) ? (kt & 1) : 0;
         const bool more = kt + 1 < KT;
-        if (STAGES == 2 && !ILV && more) fetch_dma(cur ^ 1);
+        if (STAGES == 2 && !ILV && VAR != V_PROBE_NOLD && more) fetch_dma(cur ^ 1);
         if (STAGES == 3 && kt + 2 < KT) fetch_dma(cur3 == 0 ? 2 : cur3 - 1);   // stage of tile kt-1, free since the last barrier
         constexpr int NP = NPL * (AP + BP);             // DMA instructions per tile
         constexpr int NG = (BK / 16) * TM * TN;         // MFMA groups (MPG MFMAs each) per tile
         int grp = 0;
         const unsigned char *st = smem + cur * STAGE_B;
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
+        for (int s = 0; s < (VAR == V_PROBE_LDONLY ? 0 : BK / 16); ++s) {
             typedef typename std::conditional<NPL == 3, bf16x8, f16x8>::type frag_t;
             frag_t fa[NPL][TM], fb[NPL][TN];
 #pragma unroll
@@ -506,6 +508,8 @@ static const TileInfo kTilesX3[X3_TILE_COUNT] = {
     {256, 128, 16, 32}, {128, 128, 8, 32},                                        // 28..29: two-plane timing probes (A fetched for tap 0 only)
     {128, 128, 8, 32}, {256, 128, 16, 32}, {256, 128, 8, 32}, {128, 256, 16, 32},  // 30..33: three LDS stages
     {256, 128, 16, 32}, {128, 128, 8, 32}, {256, 128, 8, 32},                      // 34..36: two-plane timing probes (K loop split over two workgroups)
+    {256, 128, 16, 32}, {128, 128, 8, 32}, {256, 128, 8, 32},                      // 37..39: two-plane timing probes (no fetches in the K loop)
+    {128, 64, 4, 32}, {128, 64, 4, 64}, {128, 128, 8, 32},                         // 40..42: two-plane timing probes (fetches only)
 };
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
@@ -614,6 +618,12 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 34: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 256x128 w16, split K
         case 35: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 128x128 w8, split K
         case 36: return launch_tp<2, 2, 2, 4, 2, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 256x128 w8, split K
+        case 37: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_NOLD>(a, out_f32, s);   // probe: 256x128 w16, no fetches in the loop
+        case 38: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_NOLD>(a, out_f32, s);   // probe: 128x128 w8
+        case 39: return launch_tp<2, 2, 2, 4, 2, 32, 2, V_PROBE_NOLD>(a, out_f32, s);   // probe: 256x128 w8
+        case 40: return launch_tp<2, 2, 1, 2, 2, 32, 2, V_PROBE_LDONLY>(a, out_f32, s);   // probe: 128x64 w4 BK32, fetches only
+        case 41: return launch_tp<2, 2, 1, 2, 2, 64, 2, V_PROBE_LDONLY>(a, out_f32, s);   // probe: 128x64 w4 BK64, fetches only
+        case 42: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_LDONLY>(a, out_f32, s);   // probe: 128x128 w8 BK32, fetches only
         default: return hipErrorInvalidValue;
     }
 }
@@ -623,7 +633,7 @@ bool conv_x3_tile_built(int tile) { return (tile >= 0 && tile <= 27) || tile == 
 bool conv_x2_tile_built(int tile)
 {
     switch (tile) {
-        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: return true;
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40: case 41: case 42: return true;
         default: return false;
     }
 }
