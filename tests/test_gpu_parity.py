@@ -910,3 +910,38 @@ def test_evaluate_driver_counters_match_oracle(rt, program, weights, anchors, tm
             assert np.array_equal(counters[k], ref.counters[k]), (thr, k)
             assert np.array_equal(one[k], ref1.counters[k]), (thr, k)
         assert counters["examples"] == 4 and counters["gts"].sum() == 8 and recall.shape == (80,)
+
+
+@pytest.mark.parametrize("mode", ["f32x2", "f32x3", "bf16"])
+def test_backbone_only_other_modes(rt, program, weights, mode):
+    """Backbone-only program in the non-fp32 modes: its outputs are residual convs that later convs read again, so they
+    are produced in the arena in the mode's format and converted to the caller's fp32 buffers at the end of the forward.
+    Plane-split modes: fp32 tolerance against the fp32 oracle; bf16: against the bf16-emulating oracle, 2^-5 of the
+    tensor's magnitude (rounding flips from a different fp32 summation order compound over up to 52 bf16 layers, and
+    the staged outputs carry one more bf16 rounding than the oracle's)."""
+    import os
+    import yaml
+    from oracle import oracle as O
+    from yolo_v3_tf2_amd import _lib
+    from yolo_v3_tf2_amd.graph import build_program, find_config_root
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mf = os.path.join(root, "config/models/yolov3/model.yaml")
+    cfg = yaml.safe_load(open(mf))
+    bb_cfg = [c for c in cfg["sub_models_configs"] if c["name"] == "backbone"]
+    bb = build_program(bb_cfg, "backbone", 0, find_config_root(mf, bb_cfg))
+    bw = {k: v for k, v in weights.items() if int(k.split(".")[0][4:]) < 52}
+    x = np.random.default_rng(2).random((3, 96, 96, 3), dtype=np.float32)
+    dt = {"f32x2": _lib.Y3_DTYPE_F32X2, "f32x3": _lib.Y3_DTYPE_F32X3, "bf16": _lib.Y3_DTYPE_BF16}[mode]
+    ref = O.forward(bb, bw, x, bf16=(mode == "bf16"))
+    net = rt.Net(bb)
+    net.load_weights(bw)
+    net.plan(3, 96, dt)
+    for lanes in (1, 2):
+        net.set_lanes(lanes)
+        got = net.forward(_cuda(x))
+        torch.cuda.synchronize()
+        for r, g in zip(ref, got):
+            g = g.cpu().numpy().reshape(r.shape)
+            scale = max(1.0, float(np.abs(r).max()))
+            tol = (2.0 ** -5 if mode == "bf16" else 1e-4) * scale
+            assert np.abs(g - r).max() <= tol, (mode, lanes, float(np.abs(g - r).max()), tol)

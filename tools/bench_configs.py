@@ -25,9 +25,8 @@ def main():
     x = torch.rand((B, S, S, 3), device="cuda")
     net = runtime.Net(bb)
     net.load_weights(bw)
-    # fp32 only: the config names fp32, and the backbone's outputs are residual convs, which the plane-split / bf16
-    # kernels do not support as fp32 "head" outputs
-    for tag, dt in (("f32", _lib.Y3_DTYPE_F32),):
+    # the config names fp32; the other modes are listed for comparison
+    for tag, dt in (("f32", _lib.Y3_DTYPE_F32), ("f32x3", _lib.Y3_DTYPE_F32X3), ("f32x2", _lib.Y3_DTYPE_F32X2), ("bf16", _lib.Y3_DTYPE_BF16)):
         net.plan(B, S, dt)
         for _ in range(3):
             net.forward(x)

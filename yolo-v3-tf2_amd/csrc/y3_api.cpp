@@ -84,6 +84,9 @@ struct y3_net {
     int early_chunk = 0;
     int early_ops = 0;             // (at plan time) number of leading ops that form the chunked segment
     std::vector<char> dense;       // tensor written by the chunked segment: own block, image i at i * image_bytes
+    // (non-fp32 modes) output tensors that another op reads, or that a residual / first-layer conv writes: produced in
+    // the arena in the mode's own format and converted into the caller's fp32 buffer at the end of the forward
+    std::vector<char> staged;
     // y3_net_detect scratch (grids, decoded boxes / classes / scores, selected indices, NMS workspace), sized for det_batch
     void *det_buf = nullptr;
     size_t det_bytes = 0;
@@ -545,6 +548,22 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
             touch(a.src0, i); touch(a.src1, i); touch(a.dst, i);
         }
     }
+    net->staged.assign(nt, 0);
+    if (dtype != Y3_DTYPE_F32) {
+        for (int i = 0; i < (int)net->ops.size(); ++i) {
+            const Op &o = net->ops[i];
+            if (o.kind != 0) continue;
+            const ConvSlot &c = net->convs[o.index];
+            const y3_conv_desc &d = c.d;
+            for (int k = 0; k < 3; ++k) {
+                const int out = net->outputs[k];
+                if (d.src0 == out || d.src1 == out || d.residual == out) net->staged[out] = 1;     // read again inside the net
+                if (d.dst == out && (d.residual >= 0 || c.first_layer)) net->staged[out] = 1;       // no fp32-output form of that launch
+            }
+        }
+        for (int k = 0; k < 3; ++k)
+            if (net->staged[net->outputs[k]]) last[net->outputs[k]] = (int)net->ops.size();        // alive until the final conversion
+    }
     // chunked leading segment: every op before the (early_convs)-th conv; tensors it writes get blocks of their own,
     // laid out densely by image, because they are rewritten chunk after chunk while earlier chunks' results are still live
     net->early_ops = 0;
@@ -569,7 +588,8 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
     // allocate in order of first definition; the image batch and the head grids are caller-owned
     std::vector<int> order;
     for (int t = 0; t < nt; ++t) {
-        const bool external = (t == net->input_tensor || t == net->outputs[0] || t == net->outputs[1] || t == net->outputs[2]);
+        const bool external = (t == net->input_tensor ||
+                               ((t == net->outputs[0] || t == net->outputs[1] || t == net->outputs[2]) && !net->staged[t]));
         if (first[t] >= 0 && !external) order.push_back(t);
     }
     std::sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
@@ -623,7 +643,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
     const bool x3 = net->dtype == Y3_DTYPE_F32X3;
     const bool x2 = net->dtype == Y3_DTYPE_F32X2;
     const size_t asz = bf ? 2 : x3 ? 6 : 4;   // bytes per element of an arena tensor (fp32, or 2 x fp16)
-    auto is_out = [&](int t) { return t == net->outputs[0] || t == net->outputs[1] || t == net->outputs[2]; };
+    auto is_out = [&](int t) { return (t == net->outputs[0] || t == net->outputs[1] || t == net->outputs[2]) && !net->staged[t]; };
     // element size: head grids are always fp32; the image batch is fp32 when the Cin = 3 first-layer kernel reads it
     // (a model whose input feeds an MFMA conv directly hands bf16 in bf16 mode); everything else follows the plan
     auto esz = [&](int t) -> size_t {
@@ -636,7 +656,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
         char *base = nullptr;
         if (t == net->input_tensor) base = reinterpret_cast<char *>(const_cast<float *>(images));
         for (int i = 0; i < 3 && !base; ++i)
-            if (t == net->outputs[i]) base = reinterpret_cast<char *>(grids[i]);
+            if (t == net->outputs[i] && !net->staged[t]) base = reinterpret_cast<char *>(grids[i]);
         if (base) return base + (size_t)b0 * img_elems(t) * esz(t);
         // arena tensors share blocks with other (dead) tensors of different per-image size: give every lane its
         // own 1/lanes region of the block so that concurrent sub-batches never alias
@@ -747,6 +767,19 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             else
                 return fail(Y3_ERR_INVALID, "unknown aux op kind %d", x.kind);
             if (e != hipSuccess) return fail(Y3_ERR_HIP, "aux op %d launch: %s", o.index, hipGetErrorString(e));
+        }
+    }
+    if (op_end == (int)net->ops.size()) {
+        for (int k = 0; k < 3; ++k) {
+            const int t = net->outputs[k];
+            if (!net->staged[t]) continue;
+            float *dst = grids[k] + (size_t)b0 * img_elems(t);
+            const int sp = spatial(net, t), C = net->tensors[t].channels;
+            const size_t npix = (size_t)nb * sp * sp;
+            hipError_t e = x2 ? y3::launch_x2_to_f32(ptr(t), dst, npix, C, s)
+                         : x3 ? y3::launch_x3_to_f32(ptr(t), dst, npix, C, s)
+                              : y3::launch_bf16_to_f32(ptr(t), dst, npix * C, s);
+            if (e != hipSuccess) return fail(Y3_ERR_HIP, "output %d conversion: %s", k, hipGetErrorString(e));
         }
     }
     if (ms_out) {
