@@ -131,7 +131,10 @@ y3_status y3_net_set_early_chunk(y3_net *net, int n_convs, int chunk_images);
  * Y3_DTYPE_F32X2: the same idea on the fp16 matrix cores with two planes per value, x = h + l' * 2^-11
  * (h = fp16(x), l' = fp16((x - h) * 2^11)), three partial products per product (h*h, h*l', l'*h) in two fp32
  * accumulators: representation error 2^-22 |x| (fp32: 2^-24), half the MFMAs of F32X3.  Values must stay inside the
- * fp16 range: BN-scaled weights are checked when they are set (|w| < 65504), activations are not checked. */
+ * fp16 range: BN-scaled weights are checked (|w| < 65504: y3_net_plan / y3_net_forward refuse the mode otherwise),
+ * activations are not checked.
+ * In the three non-fp32 modes an output tensor that another op of the net reads again, or that a residual conv writes,
+ * is kept in the arena in the mode's format and converted into the caller's fp32 buffer at the end of the forward. */
 y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype);
 
 /* images_dev [B,S,S,3] fp32 -> grids_dev[3], each [B,g,g,3*(5+nc)] fp32 (== [B,g,g,3,5+nc]).
