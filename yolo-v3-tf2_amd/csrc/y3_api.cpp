@@ -632,7 +632,7 @@ double y3_net_flops_per_image(const y3_net *net)
 // Enqueue the whole op list for images [b0, b0+nb) of the batch on stream s (tensor pointers offset by b0 images).
 // op_begin/op_end select a segment of the op list (-1: to the end).
 static y3_status run_slice(y3_net *net, const float *images, float *const grids[3], int b0, int nb, hipStream_t s,
-                           float *ms_out, int n_ms, int lane = 0, int lanes = 1, int op_begin = 0, int op_end = -1)
+                           float *ms_out, int n_ms, int lane = 0, int /*lanes*/ = 1, int op_begin = 0, int op_end = -1)
 {
     if (op_end < 0) op_end = (int)net->ops.size();
     auto img_elems = [&](int t) -> size_t {
@@ -665,7 +665,6 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
         if (net->dense[t]) return blk + (size_t)b0 * img_elems(t) * esz(t);
         // lane regions start at the lane's first image (scaled to the block size), 256-B aligned; blocks carry 4 KiB of slack
         const size_t off = ((size_t)((double)net->tblock[t] * b0 / net->cur_batch) + 255) & ~(size_t)255;
-        (void)lanes;
         return blk + (lane ? off : 0);
     };
     auto bytes = [&](int t) -> size_t { return (size_t)nb * img_elems(t) * esz(t); };
