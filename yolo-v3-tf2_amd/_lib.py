@@ -18,7 +18,7 @@ Y3_DTYPE_F32, Y3_DTYPE_BF16, Y3_DTYPE_F32X3, Y3_DTYPE_F32X2 = 0, 1, 2, 3
 DTYPE_TAGS = {Y3_DTYPE_F32: "f32", Y3_DTYPE_BF16: "bf16", Y3_DTYPE_F32X3: "f32x3", Y3_DTYPE_F32X2: "f32x2"}
 TILES_X2_BUILT = (0, 1, 2, 3, 4, 6, 8, 9, 10, 12, 26, 27, 30, 31, 32, 33)
 TILES_X3_BUILT = tuple(range(28)) + (30,)
-PROBE_TILES_X2 = (28, 29, 34, 35, 36, 37, 38, 39, 40, 41, 42)   # timing-only ablations, accepted by set_tile_x2, never chosen by the library   # ids of TILES_X3 instantiated for the two-plane mode
+PROBE_TILES_X2 = (28, 29, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45)   # timing-only ablations, accepted by set_tile_x2, never chosen by the library   # ids of TILES_X3 instantiated for the two-plane mode
 Y3_AUX_ADD, Y3_AUX_UPSAMPLE2X, Y3_AUX_CONCAT = 0, 1, 2
 # (BM, BN, waves, LDS stages) of every tile id of the fp32 MFMA conv kernel (mirror of kTiles in csrc/conv_f32.hip)
 TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (64, 128, 4, 2), (64, 64, 4, 2),
@@ -44,7 +44,8 @@ TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 3
             (128, 128, 8, 32), (256, 128, 16, 32), (256, 128, 8, 32), (128, 256, 16, 32),  # 30..33: three LDS stages
             (256, 128, 16, 32), (128, 128, 8, 32), (256, 128, 8, 32),                      # 34..36: two-plane split-K timing probes (wrong results)
             (256, 128, 16, 32), (128, 128, 8, 32), (256, 128, 8, 32),                      # 37..39: two-plane no-fetch timing probes (wrong results)
-            (128, 64, 4, 32), (128, 64, 4, 64), (128, 128, 8, 32)]                         # 40..42: two-plane fetch-only timing probes (wrong results)
+            (128, 64, 4, 32), (128, 64, 4, 64), (128, 128, 8, 32),                         # 40..42: two-plane fetch-only timing probes (wrong results)
+            (256, 256, 16, 32), (256, 128, 16, 32), (256, 128, 8, 32)]                     # 43..45: two-plane one-accumulator timing probes (wrong results)
 # bf16 kernel tiles: (BM, BN, waves, BK)
 TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
               (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64),

@@ -101,12 +101,14 @@ __device__ __forceinline__ void join_planes(const u32x4 (&q)[NPL], int k, float 
 //   V_PROBE_SK   timing only, WRONG RESULTS: two workgroups per output tile, each running half of the K loop
 //   V_PROBE_NOLD timing only, WRONG RESULTS: no operand fetches after the first K tile (LDS reads + MFMAs + barriers only)
 //   V_PROBE_LDONLY timing only, WRONG RESULTS: operand fetches and barriers only, no LDS reads, no MFMAs
-enum { V_BURST = 0, V_ILV = 1, V_ILV_PINNED = 2, V_PROBE_A1 = 3, V_PROBE_SK = 4, V_PROBE_NOLD = 5, V_PROBE_LDONLY = 6 };
+//   V_PROBE_1ACC timing only, WRONG RESULTS (two planes): all three products into one accumulator set -- the
+//                register budget of a single-accumulator form of the scheme, which makes 256x256 w16 tiles possible
+enum { V_BURST = 0, V_ILV = 1, V_ILV_PINNED = 2, V_PROBE_A1 = 3, V_PROBE_SK = 4, V_PROBE_NOLD = 5, V_PROBE_LDONLY = 6, V_PROBE_1ACC = 7 };
 template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int VAR = V_BURST>
 __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p)
 {
     static_assert(NPL == 2 || NPL == 3, "two fp16 planes or three bf16 planes");
-    constexpr int NACC = NPL == 2 ? 2 : 1;   // accumulator sets (two-plane scheme: cross terms carry a 2^11 scale)
+    constexpr int NACC = (NPL == 2 && VAR != V_PROBE_1ACC) ? 2 : 1;   // accumulator sets (two-plane scheme: cross terms carry a 2^11 scale)
     constexpr int MPG = NPL == 2 ? 3 : 6;    // MFMAs per (i, j, k-step) group
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
@@ -510,6 +512,7 @@ static const TileInfo kTilesX3[X3_TILE_COUNT] = {
     {256, 128, 16, 32}, {128, 128, 8, 32}, {256, 128, 8, 32},                      // 34..36: two-plane timing probes (K loop split over two workgroups)
     {256, 128, 16, 32}, {128, 128, 8, 32}, {256, 128, 8, 32},                      // 37..39: two-plane timing probes (no fetches in the K loop)
     {128, 64, 4, 32}, {128, 64, 4, 64}, {128, 128, 8, 32},                         // 40..42: two-plane timing probes (fetches only)
+    {256, 256, 16, 32}, {256, 128, 16, 32}, {256, 128, 8, 32},                     // 43..45: two-plane timing probes (one accumulator set)
 };
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
@@ -624,6 +627,9 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 40: return launch_tp<2, 2, 1, 2, 2, 32, 2, V_PROBE_LDONLY>(a, out_f32, s);   // probe: 128x64 w4 BK32, fetches only
         case 41: return launch_tp<2, 2, 1, 2, 2, 64, 2, V_PROBE_LDONLY>(a, out_f32, s);   // probe: 128x64 w4 BK64, fetches only
         case 42: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_LDONLY>(a, out_f32, s);   // probe: 128x128 w8 BK32, fetches only
+        case 43: return launch_tp<2, 2, 2, 4, 4, 32, 2, V_PROBE_1ACC>(a, out_f32, s);   // probe: 256x256 w16 (64x64 wave tiles), one accumulator set
+        case 44: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_1ACC>(a, out_f32, s);   // probe: 256x128 w16, one accumulator set
+        case 45: return launch_tp<2, 2, 2, 4, 2, 32, 2, V_PROBE_1ACC>(a, out_f32, s);   // probe: 256x128 w8, one accumulator set
         default: return hipErrorInvalidValue;
     }
 }
@@ -633,7 +639,7 @@ bool conv_x3_tile_built(int tile) { return (tile >= 0 && tile <= 27) || tile == 
 bool conv_x2_tile_built(int tile)
 {
     switch (tile) {
-        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40: case 41: case 42: return true;
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40: case 41: case 42: case 43: case 44: case 45: return true;
         default: return false;
     }
 }

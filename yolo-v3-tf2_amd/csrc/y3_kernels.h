@@ -45,7 +45,7 @@ hipError_t launch_conv_first_bf16(const ConvArgs &a, const float *w_hwio_dev, hi
 hipError_t launch_bf16_to_f32(const void *x, float *y, size_t n, hipStream_t s);
 
 // fp32-accurate path on the bf16 matrix cores, three bf16 planes per value (conv_f32x3.hip); TileInfo.stages holds BK
-static constexpr int X3_TILE_COUNT = 43;
+static constexpr int X3_TILE_COUNT = 46;
 TileInfo conv_x3_tile_info(int tile);
 hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);
 hipError_t launch_conv_first_f32x3(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
