@@ -13,10 +13,10 @@ def short(name):
     if m:
         tm, tn, wr, wc, cat, st = map(int, m.groups())
         return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{st}{',cat' if cat else ''}>"
-    m = re.search(r"conv_f32_mfma<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, (\d+), (\d+), (true|false))?", name)
+    m = re.search(r"conv_f32_mfma<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, (\d+), (\d+), (true|false|\d))?", name)
     if m:
         tm, tn, wr, wc = (int(m.group(i)) for i in range(1, 5))
-        dma = ",dma" if m.group(9) == "true" else ""
+        dma = ",dma" if m.group(9) in ("true", "1") else ""
         return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{m.group(6)}{dma}{',cat' if m.group(5) == 'true' else ''}>"
     m = re.search(r"conv_bf16_mfma<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)", name)
     if m:
