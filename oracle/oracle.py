@@ -127,13 +127,93 @@ def round_bf16(a):
 
 
 def forward(program, weights, images, acc64=False, keep=None, bf16=False):
-    """Run the node-level graph.  images [B,S,S,3] fp32.  Returns the head grids
-    [[B,g,g,3,5+nc] x 3] (reference: core/parse_model.py:279-314 outputs).
-    `keep`: optional set of tensor ids whose values are also returned (dict) for layer tests."""
+    """Head grids [[B,g,g,3,5+nc] x 3] of the network `program` describes (reference: core/parse_model.py:279-314).
+
+    A program that records the model.yaml it was read from (`program.model_config_file`, set by the product's
+    load_program) is NOT walked: the oracle re-reads that YAML with its own interpreter (oracle/model_reader.py), so
+    the product's YAML -> graph code is not part of the checker.  Programs assembled in memory by the layer tests
+    (tests/helpers.mini_program, sub-model subsets) carry no file and are walked node by node.
+    `keep`: optional set of tensor ids (creation order: 0 = input, then one per layer that creates a tensor) whose
+    values are also returned (dict).  bf16=True emulates a bf16 pipeline: see model_reader.bf16_stored."""
+    mf = getattr(program, "model_config_file", None)
+    if mf:
+        return forward_model(mf, weights, images, program.nclasses, acc64=acc64, keep=keep, bf16=bf16)
+    return _forward_nodes(program, weights, images, acc64, keep, bf16)
+
+
+class _Numeric:
+    """model_reader backend that computes: one C call per reference layer."""
+
+    def __init__(self, weights, acc64, stored, keep):
+        self.weights, self.acc64, self.stored, self.keep = weights, acc64, stored, set(keep or ())
+        self.kept = {}
+        self.nconv = 0
+        self.ntensor = 0          # id of the last created tensor (0 = model input)
+
+    def _out(self, y):
+        self.ntensor += 1
+        if self.stored is not None and self.ntensor in self.stored:
+            y = round_bf16(y)
+        if self.ntensor in self.keep:
+            self.kept[self.ntensor] = y
+        return y
+
+    def conv(self, x, filters, size, stride, bn, leaky, pad, sub):
+        i = self.nconv
+        self.nconv += 1
+        assert pad == 1, "the reference's YAMLs all carry pad: 1 (padding='same' iff stride == 1)"
+        w = self.weights[f"conv{i}.w"]
+        assert w.shape == (size, size, x.shape[-1], filters), (i, w.shape, (size, size, x.shape[-1], filters))
+        if self.stored is not None and x.shape[-1] != 3:
+            w = round_bf16(w)      # the MFMA convs hold their weights in bf16; the Cin = 3 first layer stays fp32
+        return self._out(conv_block(x, {**{k: v for k, v in self.weights.items() if k.startswith(f"conv{i}.")},
+                                        f"conv{i}.w": w}, i, size, stride, bn, leaky, self.acc64))
+
+    def add(self, a, b):
+        return self._out(add(a, b))
+
+    def concat(self, a, b):
+        return self._out(concat(a, b))
+
+    def upsample(self, x, stride):
+        assert stride == 2
+        return self._out(upsample2x(x))
+
+    def yolo(self, x, nclasses):
+        B, g, g2, ch = x.shape
+        return self._out(x.reshape(B, g, g2, 3, ch // 3))   # Reshape((g,g,3,5+nc)), core/parse_model.py:209-210
+
+
+def forward_model(model_config_file, weights, images, nclasses, acc64=False, keep=None, bf16=False,
+                  sub_models=None, output_stage=None):
+    """The network of model_config_file, read by the oracle's own interpreter."""
+    from . import model_reader as R
+    stored = None
+    if bf16:
+        tr, outs = R.trace(model_config_file, nclasses, sub_models, output_stage, images.shape[-1])
+        stored = R.bf16_stored(tr, outs)
+    be = _Numeric(weights, acc64, stored, keep)
+    x = _c(images)
+    if bf16 and x.shape[-1] != 3:
+        x = round_bf16(x)
+    grids = R.run_model(model_config_file, nclasses, be, x, sub_models, output_stage)
+    return (grids, be.kept) if keep else grids
+
+
+def _forward_nodes(program, weights, images, acc64=False, keep=None, bf16=False):
+    """Walk an in-memory node list (duck-typed: .nodes with kind/inputs/output/..., .ops, .outputs)."""
     vals = {program.input_tensor: _c(images)}
     if bf16:
-        from yolo_v3_tf2_amd.graph import ConvOp
-        materialised = {o.dst for o in program.ops if isinstance(o, ConvOp)} - set(program.outputs)
+        convs = [o for o in program.ops if hasattr(o, "conv_index")]
+        materialised = {o.dst for o in convs}
+        # a network output is produced in fp32 straight from the accumulators unless something inside the net reads
+        # it again or the launch that writes it is the first-layer kernel / carries a residual (then it is held in
+        # bf16 and converted at the end)
+        for t in program.outputs:
+            read_again = any(t in (o.src0, o.src1, o.residual) for o in convs)
+            special = any(o.dst == t and (o.residual >= 0 or o.cin == 3) for o in convs)
+            if not (read_again or special):
+                materialised.discard(t)
         weights = dict(weights)
         for n in program.conv_nodes:
             if program.tensors[n.inputs[0]].channels != 3:

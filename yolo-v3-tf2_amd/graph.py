@@ -113,6 +113,7 @@ class Program:
     outputs: List[int]              # head outputs in model order (13, 26, 52 grid)
     nclasses: int
     conv_nodes: List[Node] = field(default_factory=list)
+    model_config_file: Optional[str] = None   # the model.yaml this program was read from (load_program)
 
     def conv_ops(self) -> List[ConvOp]:
         return [o for o in self.ops if isinstance(o, ConvOp)]
@@ -306,7 +307,9 @@ def load_program(model_config_file: str, nclasses: int = 80) -> Program:
     with open(model_config_file, "r") as f:
         cfg = yaml.safe_load(f)
     root = find_config_root(model_config_file, cfg["sub_models_configs"])
-    return build_program(cfg["sub_models_configs"], cfg.get("output_stage", "head"), nclasses, root)
+    prog = build_program(cfg["sub_models_configs"], cfg.get("output_stage", "head"), nclasses, root)
+    prog.model_config_file = os.path.abspath(model_config_file)
+    return prog
 
 
 # ----------------------------------------------------------------------------
