@@ -205,7 +205,9 @@ y3_status y3_pack_detections(const float *bboxes_dev, const int64_t *class_idx_d
  * (reference: inference.py:109-117, 125-128, 21-28) = y3_net_forward -> y3_yolo_decode_scores -> y3_nms_padded ->
  * y3_pack_detections on net-owned scratch.  images_dev [batch,S,S,3] fp32; anchors_host [3][3][2];
  * packed_dev [batch,max_boxes,7] 32-bit words {xmin,ymin,xmax,ymax,score,class(int32),index(int32)}, rows >= num_valid
- * zeroed; num_valid_dev [batch] int32.  Everything is enqueued on `stream`.
+ * zeroed; num_valid_dev [batch] int32.  max_boxes in [1,1024].  Everything is enqueued on `stream`: the scratch (grids,
+ * decoded tensors, NMS workspace) is allocated by y3_net_plan for max_batch images, so the call allocates nothing and
+ * may be the first thing captured into a HIP graph.
  * ---------------------------------------------------------------------------------------- */
 y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const float *anchors_host, int max_boxes,
                         float iou_threshold, float score_threshold, void *packed_dev, int32_t *num_valid_dev,

@@ -263,6 +263,41 @@ def _yolo_outputs(program):
     return outs
 
 
+# ---------------------------------------------------------------------------- image input (config 1)
+def decode_image_rgb01(path):
+    """tf.image.decode_image(tf.io.read_file(path), channels=3, dtype=tf.float32) -- reference: inference.py:157.
+    PNG/JPEG -> uint8 RGB (an alpha channel is dropped, palette images expanded) -> value / 255 in fp32
+    (convert_image_dtype multiplies by the fp32 constant 1/255).  Pillow does the container decode."""
+    from PIL import Image
+    with Image.open(path) as im:
+        u8 = np.asarray(im.convert("RGBA"), np.uint8)[:, :, :3]
+    return u8.astype(np.float32) * np.float32(1.0 / 255.0)
+
+
+def resize_bilinear(img, out_h, out_w):
+    """tf.image.resize(img, (out_h, out_w)) -- reference: inference.py:158.  Bilinear, antialias=False, half-pixel
+    centres (SURVEY.md B.5): src = (dst + 0.5) * (in / out) - 0.5; lo = max(floor(src), 0); hi = min(ceil(src), in - 1);
+    frac = src - floor(src); the kernel lerps along x on the two source rows, then along y; all in fp32."""
+    img = np.ascontiguousarray(img, np.float32)
+    H, W, Cc = img.shape
+    out = np.empty((out_h, out_w, Cc), np.float32)
+    sy, sx = np.float32(H) / np.float32(out_h), np.float32(W) / np.float32(out_w)
+    xs = (np.arange(out_w).astype(np.float32) + np.float32(0.5)) * sx - np.float32(0.5)
+    x0 = np.floor(xs)
+    xl = np.clip(x0, 0, None).astype(np.intp)
+    xh = np.minimum(np.ceil(xs), W - 1).astype(np.intp)
+    xf = (xs - x0).astype(np.float32)[:, None]
+    for y in range(out_h):
+        s = (np.float32(y) + np.float32(0.5)) * sy - np.float32(0.5)
+        y0 = np.floor(s)
+        yl, yh = int(max(y0, 0)), int(min(np.ceil(s), H - 1))
+        yf = np.float32(s - y0)
+        top = img[yl, xl] + (img[yl, xh] - img[yl, xl]) * xf
+        bot = img[yh, xl] + (img[yh, xh] - img[yh, xl]) * xf
+        out[y] = top + (bot - top) * yf
+    return out
+
+
 # ---------------------------------------------------------------------------- decode / nms
 def yolo_decode(grids, anchors_table, nclasses):
     """reference: core/yolo_decode_layer.py:15-36 -> (bboxes [B,N,4], conf [B,N,1], probs [B,N,nc])"""

@@ -38,7 +38,8 @@ def test_error_convention_without_compute():
     st = lib.y3_net_create(None, 0, None, 0, None, 0, None, 0, 0, None, 80, None)
     assert st == -1 and b"y3_net_create" in lib.y3_last_error()
     assert lib.y3_nms_workspace_bytes(0, 0) == 0
-    assert lib.y3_nms_workspace_bytes(2, 10647) == 2 * 16384 * 8
+    # sort keys [B][next pow2 of N] u64 + kept-list spill [B][N][4] f32
+    assert lib.y3_nms_workspace_bytes(2, 10647) == 2 * 16384 * 8 + 2 * 10647 * 16
     st = lib.y3_nms_padded(None, None, 1, 10, 100, 0.5, 0.1, None, None, None, 0, None)
     assert st == -1
     with pytest.raises(_lib.Y3Error):

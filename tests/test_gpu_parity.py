@@ -4,6 +4,8 @@ inputs.  Tolerances are stated per test; integer/index outputs must match bit fo
 Oracle status: PARITY UNPINNED (TensorFlow absent, reference ships no golden outputs) -- see
 oracle/y3_oracle.c and DESIGN.md.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -310,6 +312,12 @@ def _bf16_ulp(x):
     return 2.0 ** -8 * max(1.0, float(np.abs(x).max()))
 
 
+def _bf16_ulp_elem(a, b):
+    """Per element: the spacing of bf16 numbers (8 significand bits) in the binade of the larger of |a|, |b|."""
+    m = np.maximum(np.maximum(np.abs(a), np.abs(b)), np.float32(2.0 ** -126)).astype(np.float64)
+    return np.ldexp(1.0, np.floor(np.log2(m)).astype(np.int64) - 7)
+
+
 @pytest.mark.parametrize("case", range(len(BF16_CASES)))
 def test_bf16_conv_layers_match_bf16_oracle(rt, case):
     """bf16 MFMA conv vs the oracle run with the same roundings (bf16 weights/activations, fp32 arithmetic).
@@ -381,25 +389,148 @@ def test_bf16_intermediate_tensors_within_one_ulp(rt, program, weights):
 
 
 def test_bf16_network_deviation_is_reported(rt, program, weights, anchors):
-    """Full network in bf16 vs (a) the bf16-emulating oracle (kernel correctness) and (b) the fp32 oracle (what bf16
-    costs).  The 1e-4 box bar of north_star is an fp32 statement; bf16 deviations are measured and bounded here."""
+    """Full network in bf16, free running, vs (a) the bf16-emulating oracle and (b) the fp32 oracle (what bf16 costs).
+
+    What bounds (a): two bf16 pipelines that differ ONLY in the order of their fp32 partial sums do not stay within a
+    few ulp of each other over 75 layers.  A perturbation of relative size e << ulp crosses a rounding boundary with
+    probability e/ulp and then costs a whole ulp, so its rms after one rounding is sqrt(e * ulp) >> e: the fixed point
+    of e -> sqrt(e * ulp) is e = ulp, and the two runs decorrelate to ~1 ulp rms (2^-8 relative) within ~10 layers.
+    tests/test_oracle.py::test_bf16_free_running_floor shows this on the CPU alone (the oracle against itself with
+    fp64 partial sums: 60-75 % of the elements differ from conv12 on, head logits differ by 4.6e-3 ... 5.5e-3 rel).
+    The bar here is therefore that floor, measured in this very test: the kernel must be no further from the oracle
+    than twice the oracle is from itself.  The per-layer kernel-correctness bar (every element within one ulp of the
+    oracle's value on the same inputs) is test_bf16_every_layer_teacher_forced_within_one_ulp.
+    The 1e-4 box bar of north_star is an fp32 statement; (b) is reported and bounded."""
     from yolo_v3_tf2_amd import _lib
     from oracle import oracle as O
     S, B = 96, 2
     x = np.random.default_rng(1234).random((B, S, S, 3), dtype=np.float32)
     ref16 = O.forward(program, weights, x, bf16=True)
+    ref16b = O.forward(program, weights, x, bf16=True, acc64=True)      # same roundings, other summation
     ref32 = O.forward(program, weights, x)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    floor_rel = max(rel(a, b) for a, b in zip(ref16b, ref16))
+    floor_max = max(float(np.abs(a - b).max()) for a, b in zip(ref16b, ref16))
     net = rt.Net(program)
     net.load_weights(weights)
     net.plan(B, S, _lib.Y3_DTYPE_BF16)
     got = [g.cpu().numpy() for g in net.forward(_cuda(x))]
     d16 = max(float(np.abs(g - r).max()) for g, r in zip(got, ref16))
     d32 = max(float(np.abs(g - r).max()) for g, r in zip(got, ref32))
-    rel16 = max(float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(got, ref16))
-    rel32 = max(float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(got, ref32))
-    print(f"bf16 head logits: vs bf16-oracle max {d16:.3e} rel {rel16:.3e}; vs fp32-oracle max {d32:.3e} rel {rel32:.3e}")
-    assert rel16 < 1.5e-2 and d16 < 0.15         # summation-order rounding flips only
+    rel16 = max(rel(g, r) for g, r in zip(got, ref16))
+    rel32 = max(rel(g, r) for g, r in zip(got, ref32))
+    print(f"bf16 head logits: vs bf16-oracle max {d16:.3e} rel {rel16:.3e} (oracle-vs-oracle floor: max {floor_max:.3e} "
+          f"rel {floor_rel:.3e}); vs fp32-oracle max {d32:.3e} rel {rel32:.3e}")
+    assert 2e-3 < floor_rel < 1.5e-2
+    assert rel16 <= 2.0 * floor_rel and d16 <= 3.0 * floor_max
     assert rel32 < 3e-2 and d32 < 0.5          # bf16 quantisation through 75 layers
+
+
+def test_bf16_every_layer_teacher_forced_within_one_ulp(rt, program, weights):
+    """Kernel-correctness bar of the bf16 path, layer by layer on the real network: every fused launch is recomputed by
+    the oracle FROM THE DEVICE'S OWN INPUT TENSORS (bf16 values are exact in fp32), rounded where the kernel rounds,
+    and compared with the device's output: every element within one bf16 ulp, and at most 0.2 % of the elements
+    different at all (a different fp32 summation order may flip a rounding; nothing else may differ).
+    The free-running comparison (test_bf16_network_deviation_is_reported) cannot be this tight: two bf16 pipelines
+    that differ by one flipped rounding decorrelate to ~1 ulp rms within a few layers (see that test)."""
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    S, B = 96, 2
+    x = np.random.default_rng(31).random((B, S, S, 3), dtype=np.float32)
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.keep_activations(True)
+    net.plan(B, S, _lib.Y3_DTYPE_BF16)
+    grids = net.forward(_cuda(x))
+    torch.cuda.synchronize()
+    outs = {t: g.cpu().numpy().reshape(B, g.shape[1], g.shape[2], -1) for t, g in zip(program.outputs, grids)}
+
+    def dev(t):
+        return x if t == program.input_tensor else net.read_tensor(t, B).cpu().numpy()
+
+    worst_frac, worst_ulp = 0.0, 0.0
+    for o in program.conv_ops():
+        a = dev(o.src0)
+        if o.src0_upsample:
+            a = O.upsample2x(a)
+        if o.src1 >= 0:
+            a = O.concat(a, dev(o.src1))
+        i = o.conv_index
+        w = {k: v for k, v in weights.items() if k.startswith(f"conv{i}.")}
+        if o.cin != 3:
+            w[f"conv{i}.w"] = O.round_bf16(w[f"conv{i}.w"])
+        y = O.conv_block(a, w, i, o.size, o.stride, o.bn, o.leaky)
+        if o.residual >= 0:
+            y = O.add(dev(o.residual), y)
+        if o.dst in outs:                                   # head conv: fp32 straight from the accumulators
+            got = outs[o.dst]
+            assert np.abs(got - y).max() <= 2e-5 * max(1.0, float(np.abs(y).max())), i
+            continue
+        exp = O.round_bf16(y)
+        got = net.read_tensor(o.dst, B).cpu().numpy()
+        diff = np.abs(got.astype(np.float64) - exp.astype(np.float64))
+        ulp = _bf16_ulp_elem(got, exp)
+        assert (diff <= ulp).all(), (i, float((diff / ulp).max()))
+        frac = float((diff > 0).mean())
+        worst_frac, worst_ulp = max(worst_frac, frac), max(worst_ulp, float((diff / ulp).max()))
+        assert frac <= 2e-3, (i, frac)
+    print(f"bf16 teacher-forced: worst per-layer mismatch fraction {worst_frac:.2e}, worst error {worst_ulp:.2f} ulp")
+
+
+def test_bf16_full_size_batch128_graph_replay(rt, program, weights, anchors):
+    """BASELINE config 5 per-GPU geometry: bf16, 128 x 416^2, the per-batch pipeline replayed from a HIP graph.
+    Size-independent properties: replay == eager bit for bit, determinism across replays, batch independence (image i
+    of the batch == the same image alone), detect rows sorted and above the threshold; images 0 and 127 against the
+    bf16-emulating oracle at the free-running bar (relative L2 of the head logits; see the teacher-forced test for the
+    per-layer ulp bar)."""
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    B, S = 128, 416
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand((B, S, S, 3), generator=gen, device="cuda")
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(B, S, _lib.Y3_DTYPE_BF16)
+    grids = [torch.empty((B, g, g, 3, 85), device="cuda") for g in net.grid_sizes()]
+
+    def step():
+        net.forward(x, out=grids)
+        bb, cls, sc = rt.yolo_decode_scores(grids, anchors, 80)
+        sel, nv = rt.nms_padded(bb, sc, 100, 0.5, 0.1)
+        return rt.pack_detections(bb, cls, sc, sel, nv), nv
+
+    ep, en = step()
+    ep, en = ep.clone(), en.clone()
+    eg = [g.clone() for g in grids]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gp, gn = step()
+    for g in grids:
+        g.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gp, ep) and torch.equal(gn, en) and all(torch.equal(a, b) for a, b in zip(grids, eg))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gp, ep) and torch.equal(gn, en)
+    for i in (0, 77, B - 1):
+        gi = net.forward(x[i:i + 1].contiguous())
+        assert all(torch.equal(a[i:i + 1], b) for a, b in zip(eg, gi)), i
+    pb, ps, pc, pi = rt.unpack_detections(ep)
+    psn, nvn = ps.cpu().numpy(), en.cpu().numpy()
+    assert nvn.min() >= 0 and nvn.max() <= 100
+    for i in range(B):
+        s_ = psn[i, :nvn[i]]
+        assert (s_ > 0.1).all() and (np.diff(s_) <= 0).all()
+    for i in (0, B - 1):
+        ref = O.forward(program, weights, x[i:i + 1].cpu().numpy(), bf16=True)
+        rel = max(float(np.linalg.norm(g[i:i + 1].cpu().numpy() - r) / np.linalg.norm(r)) for g, r in zip(eg, ref))
+        assert rel < 1.5e-2, (i, rel)
 
 
 # ---------------------------------------------------------------------------------------------- network
@@ -547,6 +678,79 @@ def test_608_grids_match_oracle(rt, program, weights):
         assert np.abs(g.cpu().numpy() - r).max() <= 1e-4
 
 
+def test_608_end_to_end_detect(rt, program, weights, anchors):
+    """BASELINE config 3 pipeline at its own resolution (608x608, N = 22743 boxes): boxes / scores within 1e-4 of the
+    oracle's, NMS bit-exact on the device's own boxes, gathered detections equal."""
+    from oracle import oracle as O
+    x = np.random.default_rng(6080).random((1, 608, 608, 3), dtype=np.float32)
+    rb, rc, rs, rsel, rnv = O.detect(program, weights, x, anchors, 100, 0.5, 0.1)
+    net = rt.Net(program)
+    net.load_weights(weights)
+    grids = net.forward(_cuda(x))
+    bb, cls, sc = rt.yolo_decode_scores(grids, anchors, 80)
+    sel, nv = rt.nms_padded(bb, sc, 100, 0.5, 0.1)
+    gb, gs = bb.cpu().numpy(), sc.cpu().numpy()
+    assert gb.shape == (1, 22743, 4)
+    assert np.abs(gb - rb).max() <= 1e-4 and np.abs(gs - rs).max() <= 1e-4
+    s2, n2 = O.nms_padded(gb, gs, 100, 0.5, 0.1)
+    assert np.array_equal(s2, sel.cpu().numpy()) and np.array_equal(n2, nv.cpu().numpy())
+    packed, nvd = net.detect(_cuda(x), anchors, 100, 0.5, 0.1)
+    assert torch.equal(nvd, nv)
+    pb, ps, pc, pi = rt.unpack_detections(packed)
+    assert torch.equal(pi[0, :int(nv[0])], sel[0, :int(nv[0])])
+
+
+def test_full_size_608_batch64_properties(rt, program, weights, anchors):
+    """BASELINE config 3 at its own size: 64 x 608^2, fp32 -- the geometry whose first activations (64 x 608^2 x 32 x 4 B
+    = 3.03 GB, 64 x 304^2 x 64 x 4 B = 1.51 GB) put byte offsets above 2^31.  Checks: images 0 and 63 of the batch
+    against the oracle (head grids <= 1e-4, and conv0 / conv1 / conv2 outputs of the LAST image -- the highest
+    addresses -- within 2e-5 of their magnitude), determinism, batch independence, detect == per-image runs."""
+    from oracle import oracle as O
+    B, S = 64, 608
+    gen = torch.Generator(device="cuda").manual_seed(608)
+    x = torch.rand((B, S, S, 3), generator=gen, device="cuda")
+    ops = program.conv_ops()
+    probe = [ops[0].dst, ops[1].dst, ops[2].dst]
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.keep_activations(True)
+    net.plan(B, S)
+    g1 = [t.clone() for t in net.forward(x)]
+    assert [tuple(g.shape) for g in g1] == [(B, 19, 19, 3, 85), (B, 38, 38, 3, 85), (B, 76, 76, 3, 85)]
+    for i in (0, B - 1):
+        ref, kept = O.forward(program, weights, x[i:i + 1].cpu().numpy(), keep=set(probe))
+        for r, g in zip(ref, g1):
+            assert np.abs(g[i:i + 1].cpu().numpy() - r).max() <= 1e-4, i
+        if i == B - 1:
+            for t in probe:
+                full = net.read_tensor(t, B)
+                got = full[i:i + 1].cpu().numpy()
+                del full
+                scale = max(1.0, float(np.abs(kept[t]).max()))
+                assert np.abs(got - kept[t]).max() <= 2e-5 * scale, t
+    g2 = net.forward(x)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))           # determinism
+    del g2
+    net.keep_activations(False)
+    net.plan(B, S)
+    packed, nv = net.detect(x, anchors, 100, 0.5, 0.1)
+    assert int(nv.min()) >= 0 and int(nv.max()) <= 100
+    for i in (7, B - 1):                                              # batch independence of the whole pipeline
+        gi = net.forward(x[i:i + 1].contiguous())
+        for a, b in zip(g1, gi):
+            assert float((a[i:i + 1] - b).abs().max()) <= 2e-5
+        p1, n1 = net.detect(x[i:i + 1].contiguous(), anchors, 100, 0.5, 0.1)
+        assert int(n1[0]) == int(nv[i])
+        b_a, s_a, c_a, i_a = rt.unpack_detections(packed[i:i + 1])
+        b_b, s_b, c_b, i_b = rt.unpack_detections(p1)
+        assert torch.equal(i_a, i_b) and torch.equal(c_a, c_b) and float((b_a - b_b).abs().max()) <= 1e-5
+    pb, ps, pc, pi = rt.unpack_detections(packed)
+    psn, nvn = ps.cpu().numpy(), nv.cpu().numpy()
+    for i in range(B):
+        s_ = psn[i, :nvn[i]]
+        assert (s_ > 0.1).all() and (np.diff(s_) <= 0).all() and (psn[i, nvn[i]:] == 0).all()
+
+
 def test_hipgraph_capture_replays_identically(rt, program, weights, anchors):
     """The whole per-batch pipeline (conv program incl. forked lanes, decode, NMS, pack) captured in a HIP graph."""
     x = _cuda(np.random.default_rng(9).random((4, 96, 96, 3), dtype=np.float32))
@@ -674,6 +878,80 @@ def test_nms_heavy_overlap_long_chains(rt):
     _check_nms(rt, boxes, scores, 100, 0.5, 0.1)
 
 
+def test_nms_kept_list_spills_past_lds_capacity(rt):
+    """More than 2048 surviving boxes that are never *selected* (no positive coordinate: TF counts a position as
+    selected iff any coordinate of its box is > 0): the kept list outgrows its LDS array and continues in the global
+    workspace; later candidates must still be suppressed by those spilled survivors.  Bit-exact against the oracle."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    n_neg, n_pos = 3000, 600
+    # disjoint unit cells in the negative quadrant (all survive, none is selected), highest scores
+    gx, gy = np.meshgrid(np.arange(60), np.arange(50))
+    x0 = -(gx.reshape(-1)[:n_neg] + 1.0) * 0.01
+    y0 = -(gy.reshape(-1)[:n_neg] + 1.0) * 0.01
+    neg = np.stack([x0, y0, x0 + 0.008, y0 + 0.008], -1)
+    neg[:, 2:] = np.minimum(neg[:, 2:], 0.0)
+    # lower-scored boxes: half of them copies of a (spilled) negative box nudged so that one coordinate is positive
+    # but IoU with the original stays >= 0.5 -> must be suppressed; the rest ordinary positive boxes
+    pos = np.empty((n_pos, 4))
+    src = rng.integers(2100, n_neg, n_pos // 2)         # suppressors that live in the spill region
+    pos[:n_pos // 2] = neg[src] + np.array([0.0, 0.0, 0.0005, 0.0])
+    c = rng.random((n_pos - n_pos // 2, 2)) * 0.8 + 0.1
+    wh = rng.random((n_pos - n_pos // 2, 2)) * 0.05 + 0.01
+    pos[n_pos // 2:] = np.concatenate([c - wh, c + wh], -1)
+    boxes = np.concatenate([neg, pos]).astype(np.float32)[None]
+    scores = np.concatenate([0.9 - 1e-5 * np.arange(n_neg), 0.5 - 1e-4 * rng.permutation(n_pos)]).astype(np.float32)[None]
+    perm = rng.permutation(boxes.shape[1])
+    boxes, scores = np.ascontiguousarray(boxes[:, perm]), np.ascontiguousarray(scores[:, perm])
+    rsel, rnv = O.nms_padded(boxes, scores, 100, 0.5, 0.1)
+    assert 0 < int(rnv[0]) <= 100
+    sel, nv = rt.nms_padded(_cuda(boxes), _cuda(scores), 100, 0.5, 0.1)
+    assert np.array_equal(nv.cpu().numpy(), rnv) and np.array_equal(sel.cpu().numpy(), rsel)
+    # a spilled survivor really suppressed something: without the negative boxes more positives are selected first
+    rsel2, rnv2 = O.nms_padded(np.ascontiguousarray(boxes[:, scores[0] < 0.6]), np.ascontiguousarray(scores[:, scores[0] < 0.6]), 100, 0.5, 0.1)
+    assert not np.array_equal(np.sort(scores[0][rsel[0, :rnv[0]]]), np.sort(scores[0][scores[0] < 0.6][rsel2[0, :rnv2[0]]]))
+
+
+def test_probe_tiles_are_rejected(rt, program, weights, monkeypatch):
+    """Timing-only ablation kernels (wrong results) are not reachable through the public setters."""
+    from yolo_v3_tf2_amd import _lib
+    monkeypatch.delenv("Y3_ALLOW_PROBE_TILES", raising=False)
+    net = rt.Net(program)
+    for t in _lib.PROBE_TILES:
+        with pytest.raises(rt.Y3Error, match="probe"):
+            net.set_tile(5, t)
+    for t in _lib.PROBE_TILES_X2:
+        with pytest.raises(rt.Y3Error, match="probe"):
+            net.set_tile_x2(5, t)
+    net.set_tile(5, 10)       # a real tile is fine
+    net.set_tile(5, -1)
+
+
+def test_detect_first_call_inside_graph_capture(rt, program, weights, anchors):
+    """y3_net_detect allocates nothing: planned once, its FIRST invocation can be the one that is captured."""
+    x = _cuda(np.random.default_rng(10).random((3, 96, 96, 3), dtype=np.float32))
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(3, 96)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            packed, nv = net.detect(x, anchors, 100, 0.5, 0.1)
+    torch.cuda.current_stream().wait_stream(s)
+    g.replay()
+    torch.cuda.synchronize()
+    p1, n1 = packed.clone(), nv.clone()
+    p2, n2 = net.detect(x, anchors, 100, 0.5, 0.1)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(n1, n2) and int(n1.min()) >= 0
+    with pytest.raises(rt.Y3Error, match="max_boxes"):
+        net.detect(x, anchors, 0, 0.5, 0.1)
+    with pytest.raises(rt.Y3Error, match="max_boxes"):
+        net.detect(x, anchors, 2000, 0.5, 0.1)
+
+
 def test_pack_detections(rt):
     from tests.helpers import nms_stress_set
     from oracle import oracle as O
@@ -757,23 +1035,25 @@ def test_end_to_end_detect(rt, program, weights, anchors):
 
 
 def test_inference_counterpart_config1(rt, program, weights, anchors, tmp_path):
-    """BASELINE config 1 (plumbing): the reference's YAML keys -> Inference()(**cfg) on one image file; detect.txt and
-    the gathered detections equal what the oracle produces from the same resized image."""
+    """BASELINE config 1 (plumbing): the reference's YAML keys -> Inference()(**cfg) on the reference's own test image
+    (datasets/coco2012/images/girl.png, config/detect_config_coco.yaml:11) with the config's own limits; detect.txt and
+    the gathered detections equal the committed oracle fixture (tests/golden/girl_416_detections.npz) and what the
+    oracle produces live from the same resized image."""
     import os
     import yaml
     from oracle import oracle as O
     from yolo_v3_tf2_amd.inference import Inference
-    from yolo_v3_tf2_amd.core.utils import load_image_rgb01, resize_bilinear
     from yolo_v3_tf2_amd.weights import save_weights
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = yaml.safe_load(open(os.path.join(root, "config/detect_config_coco.yaml")))
+    assert cfg["image_file_path"].endswith("girl.png") and cfg["nms_score_threshold"] == 0.1
     wpath = str(tmp_path / "w.safetensors")
     save_weights(wpath, weights)
     cfg.update(input_weights_path=wpath, output_dir=str(tmp_path / "out"),
                model_config_file=os.path.join(root, cfg["model_config_file"]),
                classes_name_file=os.path.join(root, cfg["classes_name_file"]),
                anchors_file=os.path.join(root, cfg["anchors_file"]),
-               image_file_path=os.path.join(root, cfg["image_file_path"]), nms_score_threshold=0.05)
+               image_file_path=os.path.join(root, cfg["image_file_path"]))
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
@@ -784,12 +1064,63 @@ def test_inference_counterpart_config1(rt, program, weights, anchors, tmp_path):
     bboxes, classes, scores, names = results[0]
     lines = open(os.path.join(cfg["output_dir"], "detect.txt")).read().strip().splitlines()
     assert len(lines) == 1 and lines[0].startswith("[") and os.path.exists(os.path.join(cfg["output_dir"], "detect_0.jpg"))
-    img = resize_bilinear(load_image_rgb01(cfg["image_file_path"]), 416, 416)[None]
-    rb, rc, rs, rsel, rnv = O.detect(program, weights, img, anchors, 100, 0.5, 0.05)
+    d = np.load(os.path.join(root, "tests/golden/girl_416_detections.npz"))
+    assert len(bboxes) == int(d["num_valid"][0]) and np.array_equal(classes, d["classes"])
+    assert np.abs(bboxes - d["boxes"]).max() <= 1e-4 and np.abs(scores - d["scores"]).max() <= 1e-4
+    img = O.resize_bilinear(O.decode_image_rgb01(cfg["image_file_path"]), 416, 416)[None]
+    rb, rc, rs, rsel, rnv = O.detect(program, weights, img, anchors, 100, 0.5, 0.1)
     ob, oc, os_ = O.gather_valid(rb[0], rc[0], rs[0], rsel[0], rnv[0])
     assert len(bboxes) == len(ob) and np.array_equal(classes, oc)
     assert np.abs(bboxes - ob).max() <= 1e-4 and np.abs(scores - os_).max() <= 1e-4
     assert lines[0].count("%") == len(ob)
+
+
+def test_plugin_surface_composition(rt, program, weights, anchors):
+    """The reference's own composition, executed on the GPU through the drop-in modules (reference: inference.py:109-115):
+        grids = model(x); decoded = yolo_decode(grids, anchors_table, nclasses); out = YoloNmsLayer(100, .5, .1)(decoded)
+    Every stage against the oracle; and the fused one-kernel decode+score path gives the identical 5-tuple."""
+    from oracle import oracle as O
+    from yolo_v3_tf2_amd.core.parse_model import Input, ParseModel
+    from yolo_v3_tf2_amd.core.yolo_decode_layer import yolo_decode
+    from yolo_v3_tf2_amd.core.yolo_nms import yolo_nms
+    from yolo_v3_tf2_amd.core.yolo_nms_layer import YoloNmsLayer
+    from yolo_v3_tf2_amd.inference import DetectModel
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config/models/yolov3/model.yaml")))
+    model = ParseModel().build_model(Input(shape=(None, None, 3)), cfg["sub_models_configs"], cfg["output_stage"],
+                                     nclasses=80, config_root=root)
+    model.set_weights_dict(weights)
+    x = np.random.default_rng(77).random((3, 96, 96, 3), dtype=np.float32)
+    grids = model(x)                                                         # inference.py:109
+    ref_grids = O.forward(program, weights, x)
+    for g, r in zip(grids, ref_grids):
+        assert tuple(g.shape) == r.shape and np.abs(g.cpu().numpy() - r).max() <= 1e-4
+    decoded = yolo_decode(grids, anchors, 80)                                # inference.py:111
+    rb, rconf, rprobs = O.yolo_decode(ref_grids, anchors, 80)
+    assert [tuple(t.shape) for t in decoded] == [rb.shape, rconf.shape, rprobs.shape]
+    assert np.abs(decoded[0].cpu().numpy() - rb).max() <= 1e-4
+    assert np.abs(decoded[1].cpu().numpy() - rconf).max() <= 1e-4 and np.abs(decoded[2].cpu().numpy() - rprobs).max() <= 1e-4
+    layer = YoloNmsLayer(100, 0.5, 0.1, name="nms")                          # inference.py:114
+    out = layer(decoded)                                                     # inference.py:115
+    assert len(out) == 5
+    bboxes, cls, scores, sel, nv = (t.cpu().numpy() for t in out)
+    assert cls.dtype == np.int64 and sel.dtype == np.int32 and nv.dtype == np.int32 and sel.shape == (3, 100)
+    # NMS is defined on identical inputs: the oracle NMS of the device's own decoded tensors, bit-exact
+    ob, ocls, osc, osel, onv = O.yolo_nms(tuple(t.cpu().numpy() for t in decoded), 100, 0.5, 0.1)
+    assert np.array_equal(cls, ocls) and np.array_equal(scores, osc) and np.array_equal(sel, osel) and np.array_equal(nv, onv)
+    assert np.array_equal(bboxes, ob)
+    # end to end against the oracle's own pipeline: values within the 1e-4 bar
+    eb, ecls, esc, esel, env_ = O.detect(program, weights, x, anchors, 100, 0.5, 0.1)
+    assert np.abs(bboxes - eb).max() <= 1e-4 and np.abs(scores - esc).max() <= 1e-4
+    # the function form and the two DetectModel routes
+    out_fn = yolo_nms(decoded, 100, 0.5, 0.1)
+    assert all(torch.equal(a, b) for a, b in zip(out, out_fn))
+    for fused in (False, True):
+        dm = DetectModel(model, anchors, 80, 100, 0.5, 0.1, fused=fused)
+        got = dm.predict(x)
+        for a, b in zip(got, (bboxes, cls, scores, sel, nv)):
+            assert np.array_equal(a, b), fused
 
 
 def test_backbone_only_config2(rt, program, weights):
@@ -916,9 +1247,9 @@ def test_evaluate_driver_counters_match_oracle(rt, program, weights, anchors, tm
 def test_backbone_only_other_modes(rt, program, weights, mode):
     """Backbone-only program in the non-fp32 modes: its outputs are residual convs that later convs read again, so they
     are produced in the arena in the mode's format and converted to the caller's fp32 buffers at the end of the forward.
-    Plane-split modes: fp32 tolerance against the fp32 oracle; bf16: against the bf16-emulating oracle, 2^-5 of the
-    tensor's magnitude (rounding flips from a different fp32 summation order compound over up to 52 bf16 layers, and
-    the staged outputs carry one more bf16 rounding than the oracle's)."""
+    Plane-split modes: fp32 tolerance against the fp32 oracle; bf16: against the bf16-emulating oracle (which rounds the
+    staged outputs like the kernel does), within three times the free-running floor -- the oracle's own deviation from
+    itself when only the order of its fp32 partial sums changes (test_bf16_network_deviation_is_reported)."""
     import os
     import yaml
     from oracle import oracle as O
@@ -933,6 +1264,10 @@ def test_backbone_only_other_modes(rt, program, weights, mode):
     x = np.random.default_rng(2).random((3, 96, 96, 3), dtype=np.float32)
     dt = {"f32x2": _lib.Y3_DTYPE_F32X2, "f32x3": _lib.Y3_DTYPE_F32X3, "bf16": _lib.Y3_DTYPE_BF16}[mode]
     ref = O.forward(bb, bw, x, bf16=(mode == "bf16"))
+    floor = None
+    if mode == "bf16":   # free-running floor: the oracle against itself with another summation (see the deviation test)
+        refb = O.forward(bb, bw, x, bf16=True, acc64=True)
+        floor = [float(np.abs(a - b).max()) for a, b in zip(refb, ref)]
     net = rt.Net(bb)
     net.load_weights(bw)
     net.plan(3, 96, dt)
@@ -940,8 +1275,8 @@ def test_backbone_only_other_modes(rt, program, weights, mode):
         net.set_lanes(lanes)
         got = net.forward(_cuda(x))
         torch.cuda.synchronize()
-        for r, g in zip(ref, got):
+        for k, (r, g) in enumerate(zip(ref, got)):
             g = g.cpu().numpy().reshape(r.shape)
             scale = max(1.0, float(np.abs(r).max()))
-            tol = (2.0 ** -5 if mode == "bf16" else 1e-4) * scale
+            tol = 3.0 * floor[k] if mode == "bf16" else 1e-4 * scale
             assert np.abs(g - r).max() <= tol, (mode, lanes, float(np.abs(g - r).max()), tol)

@@ -42,6 +42,26 @@ def test_golden_end_to_end(program, weights, anchors):
         assert np.allclose(gs, d[f"scores{i}"], atol=1e-6)
 
 
+def test_golden_config1_girl_png(program, weights, anchors):
+    """BASELINE config 1 on the reference's own test image (datasets/coco2012/images/girl.png, 812 x 667 RGBA; reference:
+    config/detect_config_coco.yaml:11, inference.py:157-163): decode -> bilinear 416^2 -> network -> decode/NMS ->
+    gathered detections equal the committed fixture (tools/gen_golden.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = np.load(os.path.join(G, "girl_416_detections.npz"))
+    raw = O.decode_image_rgb01(os.path.join(root, "datasets/coco2012/images/girl.png"))
+    assert raw.shape == (667, 812, 3) and raw.dtype == np.float32 and 0.0 <= raw.min() and raw.max() <= 1.0
+    img = O.resize_bilinear(raw, 416, 416)
+    assert np.array_equal(img[::52, ::52], d["input_probe"]) and abs(img.astype(np.float64).sum() - float(d["input_sum"])) < 1e-6
+    M, Tt, S = int(d["params"][0]), float(d["params"][1]), float(d["params"][2])
+    bb, cc, ss, sl, nv = O.detect(program, weights, img[None], anchors, M, Tt, S)
+    assert np.array_equal(nv, d["num_valid"]) and np.array_equal(sl[0, :nv[0]], d["sel"])
+    gb, gc, gs = O.gather_valid(bb[0], cc[0], ss[0], sl[0], nv[0])
+    assert np.array_equal(gc, d["classes"]) and np.abs(gb - d["boxes"]).max() <= 1e-6 and np.abs(gs - d["scores"]).max() <= 1e-6
+    # the host-side input stage of the product (core/utils.py) is a second statement of the same two TF ops
+    from yolo_v3_tf2_amd.core.utils import load_image_rgb01, resize_bilinear
+    assert np.array_equal(resize_bilinear(load_image_rgb01(os.path.join(root, "datasets/coco2012/images/girl.png")), 416, 416), img)
+
+
 def test_decode_closed_form(anchors):
     """reference: core/yolo_decode_layer.py:4-36 written out with NumPy broadcasting."""
     rng = np.random.default_rng(3)
@@ -103,6 +123,18 @@ def test_network_vs_torch_cpu(program, weights):
     got = O.forward(program, weights, x)
     for r, g in zip(ref, got):
         assert np.abs(g.reshape(r.shape) - r).max() <= 5e-5
+
+
+def test_network_vs_torch_ref_independent_reader(program, weights):
+    """oracle/torch_ref.py: PyTorch-CPU operators driven by the oracle's own YAML interpreter (the CPU baseline that
+    bench.py times) against the C restatement."""
+    from oracle import torch_ref
+    x = np.random.default_rng(99).random((2, 64, 64, 3), dtype=np.float32)
+    ref = torch_ref.forward(program.model_config_file, weights, x, 80)
+    got = O.forward(program, weights, x)
+    assert [r.shape for r in ref] == [g.shape for g in got] == [(2, 2, 2, 3, 85), (2, 4, 4, 3, 85), (2, 8, 8, 3, 85)]
+    for r, g in zip(ref, got):
+        assert np.abs(g - r).max() <= 5e-5
 
 
 def test_acc64_bounds_fp32_error(program, weights):
@@ -194,3 +226,25 @@ def test_mini_program_layers_vs_torch():
     got = O.forward(p, w, x)
     for r, g in zip(ref, got):
         assert np.abs(g.reshape(r.shape) - r).max() <= 2e-5
+
+
+def test_bf16_free_running_floor(program, weights):
+    """Why a free-running bf16 comparison cannot be held to a few ulp: the bf16-emulating oracle against ITSELF with
+    fp64 instead of fp32 partial sums (same roundings, same places; only the summation changes, by ~1e-6 relative).
+    The first layers agree almost everywhere; by conv12 a third of the stored values differ, from conv20 on more than
+    half, and the head logits end 2e-3 ... 1.5e-2 apart (relative L2) -- the level measured between the HIP kernels
+    and the oracle (5.4e-3).  A value perturbed by e << ulp flips its rounding with probability e/ulp and then moves a
+    whole ulp: rms sqrt(e * ulp), whose fixed point over layers is e = ulp.  Hence the GPU tests bound the free-running
+    deviation by this floor and hold every single layer to one ulp on identical inputs (teacher forced)."""
+    x = np.random.default_rng(1234).random((1, 96, 96, 3), dtype=np.float32)
+    ops = program.conv_ops()
+    probe = {ops[i].dst for i in (0, 4, 12, 20, 40)}
+    a, ka = O.forward(program, weights, x, bf16=True, keep=probe)
+    b, kb = O.forward(program, weights, x, bf16=True, acc64=True, keep=probe)
+    frac = {i: float((ka[ops[i].dst] != kb[ops[i].dst]).mean()) for i in (0, 4, 12, 20, 40)}
+    assert frac[0] < 1e-3 and frac[4] < 0.05 and frac[12] > 0.1 and frac[20] > 0.3 and frac[40] > 0.3, frac
+    rel = [float(np.linalg.norm(u - v) / np.linalg.norm(v)) for u, v in zip(a, b)]
+    assert all(2e-3 < r < 1.5e-2 for r in rel), rel
+    # every stored value is a bf16 number in both runs (the roundings are where they should be)
+    for t in probe:
+        assert np.array_equal(O.round_bf16(ka[t]), ka[t]) and np.array_equal(O.round_bf16(kb[t]), kb[t])

@@ -53,4 +53,15 @@ for i in range(2):
     gb, gc, gs = O.gather_valid(bb[i], cc[i], ss[i], sl[i], n[i])
     out[f"boxes{i}"], out[f"classes{i}"], out[f"scores{i}"] = gb, gc, gs
 np.savez_compressed(os.path.join(G, "e2e_s64_seed4321.npz"), **out)
+# 4. BASELINE config 1 (SURVEY.md 8c last row): the reference's own test image datasets/coco2012/images/girl.png
+#    (812 x 667 RGBA, config/detect_config_coco.yaml:11) -> decode -> bilinear 416 x 416 -> seeded synthetic weights ->
+#    decode/NMS with the config's limits (100, 0.5, 0.1).  Stored: a digest of the network input and the GATHERED
+#    detections only (inference.py:21-28), not the 10647-row tensors.
+img = O.resize_bilinear(O.decode_image_rgb01(os.path.join(ROOT, "datasets/coco2012/images/girl.png")), 416, 416)
+bb, cc, ss, sl, ng = O.detect(program, weights, img[None], anchors, 100, 0.5, 0.1)
+gb, gc, gs = O.gather_valid(bb[0], cc[0], ss[0], sl[0], ng[0])
+np.savez_compressed(os.path.join(G, "girl_416_detections.npz"), input_sum=np.float64(img.astype(np.float64).sum()),
+                    input_probe=img[::52, ::52].copy(), sel=sl[0, :ng[0]], num_valid=ng, boxes=gb, classes=gc, scores=gs,
+                    params=np.array([100, 0.5, 0.1], np.float32))
+print("girl.png detections:", int(ng[0]))
 print("golden written:", sorted(os.listdir(G)), "num_valid e2e:", n)

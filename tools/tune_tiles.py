@@ -28,6 +28,13 @@ def main():
     ap.add_argument("--write", type=str, default="")
     ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3", "f32x2"], default="f32")
     a = ap.parse_args()
+    from yolo_v3_tf2_amd import _lib as _l
+    asked = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else []
+    probes_asked = [t for t in asked if t in (_l.PROBE_TILES_X2 if a.dtype == "f32x2" else _l.PROBE_TILES if a.dtype == "f32" else ())]
+    if probes_asked:
+        if a.write:
+            sys.exit(f"tiles {probes_asked} are timing-only probes (wrong results): refusing --write")
+        os.environ["Y3_ALLOW_PROBE_TILES"] = "1"     # read by y3_net_set_tile / y3_net_set_tile_x2
     B, S = a.batch, a.image_size
     p = load_program(os.path.join(ROOT, "config/models/yolov3/model.yaml"), 80)
     w = synthetic_weights(p)

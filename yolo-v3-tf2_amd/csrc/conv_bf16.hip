@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
     }
     unsigned boff[BP];
 #pragma unroll
-    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * RP + lrow) * p.K + lchunk) * 2);
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)((n0 + j * RP + lrow) * p.K + lchunk) * 2u;
 
     int tap = 0, c0 = 0;
     unsigned avoff[AP];
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
         if (CONCAT) {
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
-                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)((aoff[i] + lchunk) * 2);
-                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)((aoff1[i] + lchunk) * 2);
+                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)(aoff[i] + lchunk) * 2u;
+                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)(aoff1[i] + lchunk) * 2u;
             }
         } else {
             const int u = tap / p.ksize, v = tap - u * p.ksize;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
             for (int i = 0; i < AP; ++i) {
                 const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
                 const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                avoff[i] = ok ? (unsigned)((aoff[i] + toff) * 2) : OOB0;
+                avoff[i] = ok ? (unsigned)(aoff[i] + toff) * 2u : OOB0;
             }
         }
     };
@@ -332,13 +332,8 @@ static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
     const size_t ctile = (size_t)WR * 32 * (BN + 4) * sizeof(float);   // epilogue tile: one 32-row block per wave row
     const size_t lds = stages > ctile ? stages : ctile;
     auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, DMA>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr;  // per instantiation
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }

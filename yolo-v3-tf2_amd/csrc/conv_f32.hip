@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     }
     unsigned boff[BP];  // byte offset of this lane's piece of weight row n, k = 0
 #pragma unroll
-    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * RP + lrow) * p.K + lchunk) * 4);
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)((n0 + j * RP + lrow) * p.K + lchunk) * 4u;
 
     // walking state of the *next* K tile to fetch.  The fp32 MFMA does not co-execute with VALU work
     // (SQ_VALU_MFMA_COEXEC_CYCLES == 0 in the profile), so the K loop must issue (almost) no vector ALU
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         if (CONCAT) {
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
-                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)((aoff[i] + lchunk) * 4);
-                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)((aoff1[i] + lchunk) * 4);
+                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)(aoff[i] + lchunk) * 4u;
+                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)(aoff1[i] + lchunk) * 4u;
             }
         } else {
             const int u = tap / p.ksize, v = tap - u * p.ksize;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
             for (int i = 0; i < AP; ++i) {
                 const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
                 const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                avoff[i] = ok ? (unsigned)((aoff[i] + toff) * 4) : OOB0;
+                avoff[i] = ok ? (unsigned)(aoff[i] + toff) * 4u : OOB0;
             }
         }
     };
@@ -393,13 +393,8 @@ static hipError_t launch_k(const ConvArgs &a, hipStream_t s)
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
     const size_t lds = STAGES * (size_t)(BM + BN) * (DMA ? BK : LDS_ROW_PADDED) * sizeof(float);
     auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE, MINW, DMA>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr;  // per instantiation
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }

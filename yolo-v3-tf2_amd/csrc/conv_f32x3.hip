@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     }
     unsigned boff[BP];  // byte offset of plane 0 of weight row n, this lane's chunk
 #pragma unroll
-    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)(((n0 + j * RP + lrow) * NPL * p.K + lchunk) * 2);
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)((n0 + j * RP + lrow) * NPL * p.K + lchunk) * 2u;
 
     int tap = 0, c0 = 0;
     unsigned avoff[AP];
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
         if (CONCAT) {
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
-                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)((aoff[i] + lchunk) * 2);
-                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)((aoff1[i] + lchunk) * 2);
+                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)(aoff[i] + lchunk) * 2u;
+                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)(aoff1[i] + lchunk) * 2u;
             }
         } else {
             const int u = tap / p.ksize, v = tap - u * p.ksize;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
             for (int i = 0; i < AP; ++i) {
                 const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
                 const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                avoff[i] = ok ? (unsigned)((aoff[i] + toff) * 2) : OOB0;
+                avoff[i] = ok ? (unsigned)(aoff[i] + toff) * 2u : OOB0;
             }
         }
     };
@@ -527,13 +527,8 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
     const size_t lds = stages > ctile ? stages : ctile;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto k = conv_f32x3_mfma<NPL, TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES, VAR>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr;  // per instantiation
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tilesM * tilesN * (VAR == V_PROBE_SK ? 2 : 1)), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }

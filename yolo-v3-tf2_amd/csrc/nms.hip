@@ -11,7 +11,8 @@
 //      are returned as original indices (int32), the rest of the row is 0; num_valid = min(count, M).
 // One workgroup (256 threads) per image: threshold+compact -> bitonic sort of 64-bit
 // (score desc, index asc) keys in LDS (global scratch beyond 4096 candidates) -> chunks of 256
-// candidates: every lane tests its candidate against the kept list (LDS), builds its 256-bit
+// candidates: every lane tests its candidate against the kept list (LDS; survivors beyond KEPT_CAP spill to the
+// global workspace -- only boxes with no positive coordinate can pile up there), builds its 256-bit
 // intra-chunk suppression row, and wave 0 resolves the chunk serially with scalar bit-ops.
 // Integer/index work is exact; IoU arithmetic is fp32 without contraction.
 #include "y3_kernels.h"
@@ -72,6 +73,7 @@ struct NmsArgs {
     int32_t *num_valid;   // [B]
     u64 *ws;              // [B][P2] scratch keys, P2 = next pow2 >= N
     int P2;
+    float *spill;         // [B][N][4] kept boxes beyond KEPT_CAP
 };
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
     __shared__ u64 s_mask[NMS_THREADS * 4];
     __shared__ u64 s_alive[4];
     __shared__ int s_keptpos[NMS_THREADS];
-    __shared__ int s_cnt, s_nkept_chunk, s_nsel, s_nalive, s_overflow;
+    __shared__ int s_cnt, s_nkept_chunk, s_nsel, s_nalive;
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
     const float *scores = p.scores + (size_t)b * p.N;
     int32_t *sel = p.sel + (size_t)b * p.M;
     u64 *gkeys = p.ws + (size_t)b * p.P2;
+    float *gspill = p.spill + (size_t)b * p.N * 4;
 
     // canonicalisation flags from box [0,0] of the batch after masking (TF looks at that box only)
     const float m00 = (p.scores[0] > p.S) ? 1.0f : 0.0f;
@@ -100,7 +103,6 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
         s_cnt = 0;
         s_nsel = 0;
         s_nalive = 0;
-        s_overflow = 0;
     }
     for (int i = tid; i < p.M; i += NMS_THREADS) sel[i] = 0;
     __syncthreads();
@@ -147,9 +149,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
             if (swap_y) { const float t = mine[0]; mine[0] = mine[2]; mine[2] = t; }
             if (swap_x) { const float t = mine[1]; mine[1] = mine[3]; mine[3] = t; }
             ok = true;
-            if (!degenerate)
-                for (int a = 0; a < nalive; ++a)
+            if (!degenerate) {
+                const int nlds = min(nalive, KEPT_CAP);
+                for (int a = 0; a < nlds; ++a)
                     if (iou_tf(*reinterpret_cast<const f32x4 *>(s_kbox + a * 4), mine) >= p.T) ok = false;
+                for (int a = KEPT_CAP; a < nalive; ++a)   // spilled survivors (rare: see the header)
+                    if (iou_tf(*reinterpret_cast<const f32x4 *>(gspill + (size_t)(a - KEPT_CAP) * 4), mine) >= p.T) ok = false;
+            }
         }
         *reinterpret_cast<f32x4 *>(s_cbox + tid * 4) = mine;
         const u64 bal = __ballot(ok);
@@ -168,21 +174,15 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
         if (tid < 64) {
             // wave 0, every lane redundantly (uniform control flow): walk the alive bits in order
             u64 w0 = s_alive[0], w1 = s_alive[1], w2 = s_alive[2], w3 = s_alive[3];
-            int nsel = s_nsel, nk = 0, nal = nalive;
+            int nsel = s_nsel, nk = 0;
             bool full = false;
             for (int w = 0; w < 4 && !full; ++w) {
                 u64 rem = (w == 0) ? w0 : (w == 1) ? w1 : (w == 2) ? w2 : w3;
                 while (rem) {
                     const int i = __builtin_ctzll(rem);
                     const int t = w * 64 + i;
-                    if (nal >= KEPT_CAP && !degenerate) {
-                        if (tid == 0) s_overflow = 1;
-                        full = true;
-                        break;
-                    }
                     if (tid == 0) s_keptpos[nk] = t;
                     ++nk;
-                    ++nal;
                     const f32x4 cb = *reinterpret_cast<const f32x4 *>(s_cbox + t * 4);
                     if (cb[0] > 0.0f || cb[1] > 0.0f || cb[2] > 0.0f || cb[3] > 0.0f) {
                         if (tid == 0) sel[nsel] = (int32_t)(unsigned)(keys[pos + t] & 0xFFFFFFFFull);
@@ -209,13 +209,15 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
         const int nk = s_nkept_chunk;
         if (tid < nk && !degenerate) {
             const int t = s_keptpos[tid];
-            *reinterpret_cast<f32x4 *>(s_kbox + (nalive + tid) * 4) = *reinterpret_cast<const f32x4 *>(s_cbox + t * 4);
+            const int slot = nalive + tid;
+            float *dst = slot < KEPT_CAP ? s_kbox + slot * 4 : gspill + (size_t)(slot - KEPT_CAP) * 4;
+            *reinterpret_cast<f32x4 *>(dst) = *reinterpret_cast<const f32x4 *>(s_cbox + t * 4);
         }
         if (tid == 0) s_nalive = nalive + nk;
         __syncthreads();
-        if (s_nsel >= p.M || s_overflow) break;
+        if (s_nsel >= p.M) break;
     }
-    if (tid == 0) p.num_valid[b] = s_overflow ? -1 : s_nsel;
+    if (tid == 0) p.num_valid[b] = s_nsel;
 }
 
 static int next_pow2(int n)
@@ -225,12 +227,18 @@ static int next_pow2(int n)
     return p;
 }
 
-size_t nms_workspace_bytes(int B, int N) { return (size_t)B * next_pow2(N > 1 ? N : 1) * sizeof(u64); }
+// sort keys [B][P2] u64, then the kept-list spill [B][N][4] f32
+size_t nms_workspace_bytes(int B, int N)
+{
+    return (size_t)B * next_pow2(N > 1 ? N : 1) * sizeof(u64) + (size_t)B * (N > 1 ? N : 1) * 4 * sizeof(float);
+}
 
 hipError_t launch_nms(const float *boxes, const float *scores, int B, int N, int M, float T, float S, int32_t *sel,
                       int32_t *num_valid, void *ws, hipStream_t s)
 {
-    NmsArgs a{boxes, scores, N, M, T, S, sel, num_valid, static_cast<u64 *>(ws), next_pow2(N > 1 ? N : 1)};
+    const int P2 = next_pow2(N > 1 ? N : 1);
+    u64 *keys = static_cast<u64 *>(ws);
+    NmsArgs a{boxes, scores, N, M, T, S, sel, num_valid, keys, P2, reinterpret_cast<float *>(keys + (size_t)B * P2)};
     dim3 grid(B), block(NMS_THREADS);
     hipLaunchKernelGGL(nms_kernel, grid, block, 0, s, a);
     return hipGetLastError();

@@ -64,6 +64,7 @@ struct Op {
 };
 
 constexpr int Y3_MAX_LANES = 4;
+constexpr int Y3_MAX_OUTPUT_BOXES = 1024;   // upper bound of max_output_size (y3_nms_padded) the detect scratch is sized for
 
 }  // namespace
 
@@ -87,7 +88,8 @@ struct y3_net {
     // (non-fp32 modes) output tensors that another op reads, or that a residual / first-layer conv writes: produced in
     // the arena in the mode's own format and converted into the caller's fp32 buffer at the end of the forward
     std::vector<char> staged;
-    // y3_net_detect scratch (grids, decoded boxes / classes / scores, selected indices, NMS workspace), sized for det_batch
+    // y3_net_detect scratch (grids, decoded boxes / classes / scores, selected indices, NMS workspace): allocated by
+    // y3_net_plan for max_batch images and Y3_MAX_OUTPUT_BOXES rows, so y3_net_detect itself only enqueues work
     void *det_buf = nullptr;
     size_t det_bytes = 0;
     int cur_batch = 1;             // batch of the forward being enqueued
@@ -162,6 +164,16 @@ float f16_to_f32(unsigned short h)
         v = ldexpf((float)(1024 + m), e - 25);
     return (h & 0x8000) ? -v : v;
 }
+
+// Timing-only ablation kernels (wrong results by construction) stay out of reach of the public setters unless the
+// process opts in with Y3_ALLOW_PROBE_TILES=1 (tools/tune_tiles.py --probe does).
+bool probes_allowed()
+{
+    const char *e = getenv("Y3_ALLOW_PROBE_TILES");
+    return e && e[0] == '1';
+}
+bool is_probe_tile_f32(int t) { return t == 20 || t == 21 || t == 22 || t == 25; }
+bool is_probe_tile_x2(int t) { return t == 28 || t == 29 || (t >= 34 && t <= 45); }
 
 int choose_tile_x2(const ConvSlot &c, long long M)
 {
@@ -440,6 +452,8 @@ y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
         return fail(Y3_ERR_INVALID, "y3_net_set_tile: bad argument");
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
+        if (is_probe_tile_f32(tile) && !probes_allowed())
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile %d is a timing-only probe (set Y3_ALLOW_PROBE_TILES=1 to use it)", tile);
         y3::TileInfo s = y3::conv_tile_info(tile);
         if (c.first_layer || c.cout_pad % s.bn) return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile does not divide Cout");
     }
@@ -481,6 +495,8 @@ y3_status y3_net_set_tile_x2(y3_net *net, int slot, int tile)
         return fail(Y3_ERR_INVALID, "y3_net_set_tile_x2: bad argument");
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
+        if (is_probe_tile_x2(tile) && !probes_allowed())
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_x2: tile %d is a timing-only probe (set Y3_ALLOW_PROBE_TILES=1 to use it)", tile);
         y3::TileInfo s = y3::conv_x3_tile_info(tile);
         if (!y3::conv_x2_tile_built(tile) || c.first_layer || c.cout_pad64 % s.bn || c.d.cin % s.stages ||
             (c.d.src1 >= 0 && c.d.c0 % s.stages))
@@ -510,6 +526,20 @@ y3_status y3_net_keep_activations(y3_net *net, int keep)
 {
     if (!net) return fail(Y3_ERR_INVALID, "y3_net_keep_activations: null net");
     net->keep_all = keep ? 1 : 0;
+    return Y3_OK;
+}
+
+static void detect_layout(const y3_net *net, int batch, size_t off[9], size_t *n_boxes, int32_t gs[3], size_t gelems[3]);
+
+// forked streams / events of the concurrent sub-batches: created at plan time so that a forward enqueues work only
+static y3_status ensure_lanes(y3_net *net)
+{
+    if (net->fork_ev) return Y3_OK;
+    HIP_TRY(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < Y3_MAX_LANES; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&net->lane_stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&net->join_ev[i], hipEventDisableTiming));
+    }
     return Y3_OK;
 }
 
@@ -615,7 +645,42 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
         net->tdev[t] = pool[pick].p;
         net->tblock[t] = pool[pick].bytes;
     }
+    if (y3_status st = ensure_lanes(net); st != Y3_OK) return st;
+    if (net->nclasses > 0) {   // scratch of y3_net_detect: no allocation inside the stream-ordered call
+        size_t off[9], n_boxes, gelems[3];
+        int32_t gs[3];
+        detect_layout(net, max_batch, off, &n_boxes, gs, gelems);
+        hipError_t e = hipMalloc(&net->det_buf, off[8]);
+        if (e != hipSuccess) {
+            free_plan(net);
+            return fail(Y3_ERR_OOM, "y3_net_plan: hipMalloc(%zu) for the detect scratch failed: %s", off[8], hipGetErrorString(e));
+        }
+        net->det_bytes = off[8];
+    }
     return Y3_OK;
+}
+
+// byte offsets of the y3_net_detect scratch for `batch` images (and the total in [8])
+static void detect_layout(const y3_net *net, int batch, size_t off[9], size_t *n_boxes, int32_t gs[3], size_t gelems[3])
+{
+    const size_t per = (size_t)3 * (5 + net->nclasses);
+    size_t n = 0;
+    for (int i = 0; i < 3; ++i) {
+        gs[i] = spatial(net, net->outputs[i]);
+        gelems[i] = (size_t)batch * gs[i] * gs[i] * per;
+        n += (size_t)3 * gs[i] * gs[i];
+    }
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    off[0] = 0;                                              // grid 0
+    off[1] = off[0] + up(gelems[0] * 4);                     // grid 1
+    off[2] = off[1] + up(gelems[1] * 4);                     // grid 2
+    off[3] = off[2] + up(gelems[2] * 4);                     // boxes
+    off[4] = off[3] + up((size_t)batch * n * 16);            // class indices (i64)
+    off[5] = off[4] + up((size_t)batch * n * 8);             // scores
+    off[6] = off[5] + up((size_t)batch * n * 4);             // selected indices
+    off[7] = off[6] + up((size_t)batch * Y3_MAX_OUTPUT_BOXES * 4);   // NMS workspace
+    off[8] = off[7] + y3::nms_workspace_bytes(batch, (int)n);
+    *n_boxes = n;
 }
 
 double y3_net_flops_per_image(const y3_net *net)
@@ -822,13 +887,7 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
     };
     if (lanes == 1) return run_lane(0, batch, s, 0, 1);
     HIP_TRY(hipSetDevice(net->device));
-    if (!net->fork_ev) {
-        HIP_TRY(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
-        for (int i = 0; i < Y3_MAX_LANES; ++i) {
-            HIP_TRY(hipStreamCreateWithFlags(&net->lane_stream[i], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&net->join_ev[i], hipEventDisableTiming));
-        }
-    }
+    if (y3_status st = ensure_lanes(net); st != Y3_OK) return st;
     HIP_TRY(hipEventRecord(net->fork_ev, s));
     // equal sub-batches (measured with tools/lanes_sweep.py: weighted 2:3 / 3:4:5 splits were 2-3 % slower)
     int start[Y3_MAX_LANES + 1];
@@ -1006,29 +1065,16 @@ y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const f
     if (net->nclasses <= 0) return fail(Y3_ERR_STATE, "y3_net_detect: the net was created without detection heads (nclasses = 0)");
     if (!net->image_size) return fail(Y3_ERR_STATE, "y3_net_detect: call y3_net_plan first");
     if (batch > net->max_batch) return fail(Y3_ERR_INVALID, "y3_net_detect: batch %d > planned %d", batch, net->max_batch);
+    if (max_boxes <= 0 || max_boxes > Y3_MAX_OUTPUT_BOXES)
+        return fail(Y3_ERR_INVALID, "y3_net_detect: max_boxes must be in [1,%d]", Y3_MAX_OUTPUT_BOXES);
     int32_t gs[3];
-    size_t gelems[3], n = 0;
-    const size_t per = (size_t)3 * (5 + net->nclasses);
-    for (int i = 0; i < 3; ++i) {
-        gs[i] = spatial(net, net->outputs[i]);
-        gelems[i] = (size_t)batch * gs[i] * gs[i] * per;
-        n += (size_t)3 * gs[i] * gs[i];
-    }
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_grid0 = 0, o_grid1 = o_grid0 + up(gelems[0] * 4), o_grid2 = o_grid1 + up(gelems[1] * 4);
-    const size_t o_box = o_grid2 + up(gelems[2] * 4), o_cls = o_box + up((size_t)batch * n * 16);
-    const size_t o_score = o_cls + up((size_t)batch * n * 8), o_sel = o_score + up((size_t)batch * n * 4);
-    const size_t o_ws = o_sel + up((size_t)batch * max_boxes * 4);
+    size_t gelems[3], n = 0, off[9];
+    detect_layout(net, batch, off, &n, gs, gelems);
+    if (!net->det_buf || net->det_bytes < off[8])
+        return fail(Y3_ERR_STATE, "y3_net_detect: detect scratch not planned (y3_net_plan allocates it)");
+    const size_t o_grid0 = off[0], o_grid1 = off[1], o_grid2 = off[2], o_box = off[3], o_cls = off[4], o_score = off[5];
+    const size_t o_sel = off[6], o_ws = off[7];
     const size_t ws_bytes = y3::nms_workspace_bytes(batch, (int)n);
-    const size_t need = o_ws + ws_bytes;
-    HIP_TRY(hipSetDevice(net->device));
-    if (net->det_bytes < need) {
-        if (net->det_buf) (void)hipFree(net->det_buf);
-        net->det_buf = nullptr;
-        net->det_bytes = 0;
-        HIP_TRY(hipMalloc(&net->det_buf, need));
-        net->det_bytes = need;
-    }
     char *b = static_cast<char *>(net->det_buf);
     float *grids[3] = {reinterpret_cast<float *>(b + o_grid0), reinterpret_cast<float *>(b + o_grid1),
                        reinterpret_cast<float *>(b + o_grid2)};

@@ -28,6 +28,20 @@ struct ConvArgs {
     unsigned src0_bytes, src1_bytes, w_bytes, dst_bytes;
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to the
+// device's copy of the code object, so a process driving several GPUs must set it on each.
+struct LdsAttrOnce { unsigned long long done = 0; };   // bit d: set on device d (d < 64)
+inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((st.done >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) st.done |= 1ull << dev;
+    return e;
+}
+
 // tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
 static constexpr int TILE_COUNT = 33;  // 20..22 are timing-only probes
 struct TileInfo { int bm, bn, waves, stages; };

@@ -18,24 +18,36 @@ from .core.utils import dir_filelist, get_anchors, load_image_u8
 
 
 class DetectModel:
-    """Model(inputs, nms_output, name="yolo_nms") of reference inference.py:109-117."""
+    """Model(inputs, nms_output, name="yolo_nms") of reference inference.py:109-117: the composition
+    `model(inputs)` -> `yolo_decode(grids, anchors_table, nclasses)` -> `YoloNmsLayer(max, iou, score)(decoded)`
+    through the plugin surface (core/yolo_decode_layer.py, core/yolo_nms_layer.py), exactly as the reference wires it.
+    fused=True runs the same arithmetic as one decode+score kernel that never materialises the [B,N,nclasses]
+    probabilities (what bench.py and y3_net_detect use); both give identical tuples."""
 
-    def __init__(self, model, anchors_table, nclasses, yolo_max_boxes, nms_iou_threshold, nms_score_threshold):
+    def __init__(self, model, anchors_table, nclasses, yolo_max_boxes, nms_iou_threshold, nms_score_threshold,
+                 fused=False):
+        from .core.yolo_nms_layer import YoloNmsLayer
         self.model = model
         self.anchors_table = np.asarray(anchors_table, np.float32)
         self.nclasses = nclasses
         self.yolo_max_boxes = int(yolo_max_boxes)
         self.nms_iou_threshold = float(nms_iou_threshold)
         self.nms_score_threshold = float(nms_score_threshold)
+        self.fused = bool(fused)
+        self.nms_layer = YoloNmsLayer(self.yolo_max_boxes, self.nms_iou_threshold, self.nms_score_threshold)
 
     def __call__(self, images):
         """images: [B,S,S,3] fp32 (numpy or CUDA tensor) -> the 5-tuple as CUDA tensors."""
-        from . import runtime
         grids = self.model(images)
-        bboxes, cls, scores = runtime.yolo_decode_scores(grids, self.anchors_table, self.nclasses)
-        sel, nv = runtime.nms_padded(bboxes, scores, self.yolo_max_boxes, self.nms_iou_threshold,
-                                     self.nms_score_threshold)
-        return bboxes, cls, scores, sel, nv
+        if self.fused:
+            from . import runtime
+            bboxes, cls, scores = runtime.yolo_decode_scores(grids, self.anchors_table, self.nclasses)
+            sel, nv = runtime.nms_padded(bboxes, scores, self.yolo_max_boxes, self.nms_iou_threshold,
+                                         self.nms_score_threshold)
+            return bboxes, cls, scores, sel, nv
+        from .core.yolo_decode_layer import yolo_decode
+        decoded_output = yolo_decode(grids, self.anchors_table, self.nclasses)      # reference: inference.py:111
+        return self.nms_layer(decoded_output)                                        # reference: inference.py:114-115
 
     def predict(self, images, **_):
         return tuple(t.cpu().numpy() for t in self(images))
