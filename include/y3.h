@@ -34,7 +34,8 @@ enum {
     Y3_ERR_HIP = -2,       /* HIP runtime error */
     Y3_ERR_OOM = -3,       /* device allocation failed */
     Y3_ERR_STATE = -4,     /* call order (weights missing, plan missing, ...) */
-    Y3_ERR_NODEVICE = -5   /* no usable GPU */
+    Y3_ERR_NODEVICE = -5,  /* no usable GPU */
+    Y3_ERR_COMM = -6       /* RCCL error (or librccl not loadable) */
 };
 
 /* activation storage / MFMA input type of the conv stack */
@@ -114,6 +115,12 @@ y3_status y3_net_set_tile_x2(y3_net *net, int conv_slot, int tile);   /* same ti
  * stream: the tail of one sub-batch's conv kernel overlaps the next kernel of another.  Results are unchanged
  * (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
 y3_status y3_net_set_lanes(y3_net *net, int lanes);
+/* fp32 tiles 33..40 run the persistent "stream-K" schedule: as many workgroups as the chip holds at once, each with an
+ * equal share of the (tile, K-tile) iterations; tiles cut between workgroups are summed through fp32 slabs in a
+ * net-owned workspace in a fixed order (run-to-run deterministic; the split points depend on the launch geometry, so the
+ * last bits of an image's result may depend on the batch it is in -- the classic tiles 0..32 never split a sum).
+ * y3_net_set_sk_grid: force the number of persistent workgroups (0 = everything resident at once); for tests. */
+y3_status y3_net_set_sk_grid(y3_net *net, int workgroups);
 y3_status y3_net_keep_activations(y3_net *net, int keep);
 /* Before y3_net_plan: run the first n_convs convs chunk_images images at a time, then the rest of the network on the
  * whole batch.  The first layers' activations are the largest tensors of the network (1.4 GB for 64 images at 416x416);
@@ -212,6 +219,27 @@ y3_status y3_pack_detections(const float *bboxes_dev, const int64_t *class_idx_d
 y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const float *anchors_host, int max_boxes,
                         float iou_threshold, float score_threshold, void *packed_dev, int32_t *num_valid_dev,
                         void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU exchange (no reference counterpart: the reference is single-device).
+ * One process per GPU; images are sharded by rank and are independent end to end, so the only collective of the path
+ * is the all-gather of the packed final detections (north_star: "RCCL all-gather of the final box list over xGMI").
+ *   y3_comm_get_unique_id   rank 0 draws an id (Y3_COMM_ID_BYTES bytes, host) and hands it to the other ranks by any
+ *                           out-of-band means (the Python host uses the torch.distributed store / broadcast)
+ *   y3_comm_init_rank       every rank, on its own current device: joins the communicator (ncclCommInitRank)
+ *   y3_allgather_results    packed_dev [batch,max_boxes,7] 32-bit words + num_valid_dev [batch] of this rank ->
+ *                           packed_all_dev [world*batch,max_boxes,7], num_valid_all_dev [world*batch] in rank order;
+ *                           equal batch on every rank; both gathers form ONE RCCL group enqueued on `stream`
+ *                           (capturable into the same HIP graph as y3_net_detect).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct y3_comm y3_comm;
+#define Y3_COMM_ID_BYTES 128
+y3_status y3_comm_get_unique_id(void *id_out_host);
+y3_status y3_comm_init_rank(const void *id_host, int world_size, int rank, y3_comm **out);
+void y3_comm_destroy(y3_comm *comm);
+y3_status y3_comm_info(const y3_comm *comm, int32_t *world_size, int32_t *rank);
+y3_status y3_allgather_results(y3_comm *comm, const void *packed_dev, const int32_t *num_valid_dev, int batch,
+                               int max_boxes, void *packed_all_dev, int32_t *num_valid_all_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * TFRecord framing checksum (host): CRC-32C (Castagnoli) of a host buffer, unmasked.  The tfrecords input source

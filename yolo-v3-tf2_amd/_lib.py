@@ -29,7 +29,12 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
          (128, 128, 4, 1), (128, 128, 4, 1),                # 23/24: 128x128 within 3 / 4 waves per SIMD of registers
          (64, 128, 4, 1),                                   # 25: probe 4 (timing only)
          (64, 128, 4, 2), (64, 64, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (256, 32, 4, 2),  # 26..30: LDS-DMA operand loads
-         (64, 128, 4, 1), (64, 64, 4, 1)]                   # 31, 32: LDS-DMA, single LDS stage
+         (64, 128, 4, 1), (64, 64, 4, 1),                   # 31, 32: LDS-DMA, single LDS stage
+         # 33..40: the persistent stream-K schedule of tiles 10, 11, 9, 17, 26, 27, 31, 32
+         (64, 128, 4, 1), (64, 64, 4, 1), (128, 64, 4, 1), (128, 64, 8, 1),
+         (64, 128, 4, 2), (64, 64, 4, 2), (64, 128, 4, 1), (64, 64, 4, 1)]
+SK_TILES = tuple(range(33, 41))
+SK_BASE = {33: 10, 34: 11, 35: 9, 36: 17, 37: 26, 38: 27, 39: 31, 40: 32}
 N_REAL_TILES = 20
 # three-plane (fp32-accurate on bf16 MFMA) kernel tiles: (BM, BN, waves, BK)
 TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), (256, 64, 4, 32),
@@ -52,7 +57,8 @@ TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4
               (128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (64, 128, 4, 64), (128, 256, 8, 64),  # 8..13: LDS-DMA loads
               (256, 256, 8, 64), (256, 128, 4, 64), (128, 256, 4, 64),  # 14..16: LDS-DMA, bigger wave tiles
               (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64)]  # 17..19: LDS-DMA, 16 waves
-TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if i >= 26 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
+TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if (26 <= i <= 32 or i >= 37) else "") + ("sk" if i >= 33 else "")
+              for i, (bm, bn, w, st) in enumerate(TILES)]
 PROBE_TILES = (20, 21, 22, 25)  # timing-only ablations, wrong results
 
 
@@ -93,6 +99,7 @@ SYMBOLS = {
     "y3_net_set_early_chunk": (_i, [_vp, _i, _i]),
     "y3_net_keep_activations": (_i, [_vp, _i]),
     "y3_net_set_lanes": (_i, [_vp, _i]),
+    "y3_net_set_sk_grid": (_i, [_vp, _i]),
     "y3_net_plan": (_i, [_vp, _i, _i, _i]),
     "y3_net_forward": (_i, [_vp, _vp, _i, C.POINTER(_vp), _vp]),
     "y3_net_read_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_sz), _vp]),
@@ -107,7 +114,13 @@ SYMBOLS = {
     "y3_pack_detections": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "y3_crc32c": (C.c_uint32, [_vp, C.c_size_t]),
     "y3_net_detect": (_i, [_vp, _vp, _i, _fp, _i, C.c_float, C.c_float, _vp, _vp, _vp]),
+    "y3_comm_get_unique_id": (_i, [_vp]),
+    "y3_comm_init_rank": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "y3_comm_destroy": (None, [_vp]),
+    "y3_comm_info": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "y3_allgather_results": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
 }
+Y3_COMM_ID_BYTES = 128
 
 _lib = None
 

@@ -43,7 +43,17 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 // tools/mfma_probe.hip, a 16-B load to VGPRs costs the SIMD ~8-16 cycles of matrix-pipe time and a ds_write_b128 ~13,
 // an LDS-DMA load ~4.  LDS rows are then unpadded 128 B (a wave instruction writes 8 whole rows) and bank conflicts
 // are avoided by an XOR swizzle of the 16-B chunk index applied on the SOURCE address and on the fragment reads.
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0>
+//
+// SK != 0: persistent "stream-K" schedule.  The launch has as many workgroups as the chip holds at once; the
+// (tile, K-tile) iteration space, tile-major, is cut into equal contiguous shares, so every workgroup runs the same
+// number of MFMAs and the launch ends everywhere at once instead of draining tile by tile (a conv launch is only 2.6-5.3
+// "rounds" of workgroups deep; profiles/r02_batch_scaling_f32.txt prices the drain at ~12 us per launch = 3 % of the step).
+// A tile whose K range is cut is summed through fp32 slabs in the workspace: every contributor writes its partial
+// accumulators write-through (sc1), drains, and takes a ticket on the tile's counter; whoever draws the last ticket
+// reads ALL slabs back (its own too) in contributor order -- so the sum does not depend on who arrives last -- and
+// runs the epilogue.  Nobody waits for anybody (no spinning, no residency assumption).  Protocol:
+// cdna_hip_programming.md section 5 (split-K slab reducer) / Guideline 16.
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvArgs p)
 {
     constexpr int LDS_ROW = DMA ? BK : BK + 4;  // floats per LDS row
@@ -70,9 +80,22 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int tilesN = p.CoutPad / BN;
-    const int mt = logical / tilesN, nt = logical - mt * tilesN;
-    const int m0 = mt * BM, n0 = nt * BN;
-
+    const int KT = p.K / BK;
+    // stream-K: workgroup l owns iterations [l*q + min(l,r), +q (+1 if l < r)) of the tile-major (tile, K-tile) space
+    int sk_q = 0, sk_r = 0, it = 0, it_end = 0;
+    if (SK) {
+        const int total = p.sk_tiles * KT;
+        sk_q = total / nwg;
+        sk_r = total - sk_q * nwg;
+        it = logical * sk_q + min(logical, sk_r);
+        it_end = it + sk_q + (logical < sk_r ? 1 : 0);
+    }
+    auto sk_begin_of = [&](int l) { return l * sk_q + min(l, sk_r); };
+    auto sk_owner = [&](int i) {
+        const int cut = sk_r * (sk_q + 1);
+        return i < cut ? i / (sk_q + 1) : sk_r + (i - cut) / sk_q;
+    };
+    bool first_segment = true;
     const __amdgpu_buffer_rsrc_t rs0 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.src0), 0, p.src0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -81,6 +104,23 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wpk), 0, p.w_bytes, 0x00020000);
     // a voffset equal to num_records is out of range for the buffer's bounds check -> the load returns 0
     const unsigned OOB0 = p.src0_bytes, OOB1 = CONCAT ? p.src1_bytes : p.src0_bytes;
+
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(p.residual ? p.residual : p.dst), 0, p.dst_bytes, 0x00020000);
+    const int fr = lane & 31, fh = lane >> 5;
+
+  int seg_k0 = 0, seg_k1 = KT;
+  do {   // one pass per segment = (tile, K-tile range); the classic schedule makes exactly one pass
+    int tile = logical;
+    if (SK) {
+        tile = it / KT;
+        seg_k0 = it - tile * KT;
+        seg_k1 = min(KT, seg_k0 + (it_end - it));
+        if (!first_segment) __syncthreads();   // slower waves may still read the previous segment's LDS tiles / flag
+    }
+    const int mt = tile / tilesN, nt = tile - mt * tilesN;
+    const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- per-thread gather state -------------------------------------------------------------
     const int lrow = tid >> 3;         // row inside a pass
@@ -131,7 +171,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     // (SQ_VALU_MFMA_COEXEC_CYCLES == 0 in the profile), so the K loop must issue (almost) no vector ALU
     // instructions: per-lane byte offsets are fixed per tap (out-of-image lanes hold the out-of-range
     // sentinel) and everything that changes per K tile goes into the scalar soffset of the buffer load.
-    int tap = 0, c0 = 0;
+    int kglob = seg_k0 * BK;  // k index of the next tile to fetch
+    int tap = CONCAT ? 0 : kglob / p.Cin;
+    int c0 = kglob - tap * p.Cin;
     unsigned avoff[AP];                  // voffset of this lane's piece for the current tap (or OOB0)
     unsigned avoff1[CONCAT ? AP : 1];    // CONCAT: same for src1
     auto set_tap = [&]() {
@@ -155,7 +197,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     set_tap();
 
     f32x4 ra[AP], rb[BP];
-    int kglob = 0;  // k index of the next tile to fetch
     typedef __attribute__((address_space(3))) void *lds_ptr;
     auto fetch_dma = [&](int buf) {
         // wave w fills rows [pass*RP + 8w, +8) of each tile: LDS destination = M0 base + lane*16
@@ -222,7 +263,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int KT = p.K / BK;
     if (DMA) {
         fetch_dma(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -232,7 +272,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     }
     __syncthreads();
 
-    const int fr = lane & 31, fh = lane >> 5;
     const int a_frag = (wr * 32 * TM + fr) * LDS_ROW + (DMA ? 0 : fh * 4);
     const int b_frag = BM * LDS_ROW + (wc * 32 * TN + fr) * LDS_ROW + (DMA ? 0 : fh * 4);
     int foff[4];  // float offset of this lane's k-chunk q inside its row
@@ -246,13 +285,13 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
         for (int j = 0; j < TN; ++j) pfb[j] = *reinterpret_cast<const f32x4 *>(smem + b_frag + j * 32 * LDS_ROW);
     }
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = (STAGES == 2) ? (kt & 1) : 0;
+    for (int kt = seg_k0; kt < seg_k1; ++kt) {
+        const int cur = (STAGES == 2) ? ((kt - seg_k0) & 1) : 0;
         if (DMA && STAGES == 2) {
-            if (kt + 1 < KT) fetch_dma(cur ^ 1);   // every wave passed the barrier that ended tile kt-1: buf cur^1 is free
+            if (kt + 1 < seg_k1) fetch_dma(cur ^ 1);   // every wave passed the barrier that ended tile kt-1: buf cur^1 is free
         } else if (DMA) {
         } else if (PROBE == 0 || PROBE == 3) {
-            if (kt + 1 < KT) fetch();
+            if (kt + 1 < seg_k1) fetch();
         }
         const float *sa = smem + cur * STAGE + a_frag;
         const float *sb = smem + cur * STAGE + b_frag;
@@ -282,7 +321,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 has landed (issued a whole K tile ago)
             __syncthreads();
         } else if (DMA) {
-            if (kt + 1 < KT) {
+            if (kt + 1 < seg_k1) {
                 __syncthreads();   // every wave is done reading the single buffer
                 fetch_dma(0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -300,12 +339,69 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                 for (int j = 0; j < BP; ++j) asm volatile("" ::"v"(rb[j]));
             }
         } else if (STAGES == 2) {
-            if (kt + 1 < KT) stage(cur ^ 1);
+            if (kt + 1 < seg_k1) stage(cur ^ 1);
             __syncthreads();
-        } else if (kt + 1 < KT) {
+        } else if (kt + 1 < seg_k1) {
             __syncthreads();  // every wave is done reading the tile
             stage(0);
             __syncthreads();
+        }
+    }
+
+    // ---- stream-K: a cut tile is completed by whoever contributes last -----------------------------------
+    if (SK && (seg_k0 != 0 || seg_k1 != KT)) {
+        constexpr unsigned SLAB = BM * BN * 4;                    // bytes of one partial tile: [TM*TN*4][NT] x 16 B
+        const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(p.sk_ws, 0, p.sk_ws_bytes, 0x00020000);
+        const int t_begin = tile * KT;
+        const int c_first = sk_owner(t_begin), c_last = sk_owner(t_begin + KT - 1);
+        // a workgroup has at most two cut segments: slot 0 = the one that starts its range, slot 1 = the other
+        const unsigned my_off = (unsigned)(2 * logical + (it == sk_begin_of(logical) ? 0 : 1)) * SLAB + (unsigned)tid * 16u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    // (whole-vector bit casts: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0)
+                    const f32x4 f = {acc[i][j][e4 * 4 + 0], acc[i][j][e4 * 4 + 1], acc[i][j][e4 * 4 + 2], acc[i][j][e4 * 4 + 3]};
+                    const u32x4 v = __builtin_bit_cast(u32x4, f);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsk, (int)my_off, ((i * TN + j) * 4 + e4) * NT * 16, 16);  // aux 16 = sc1: write-through
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the ticket
+        __syncthreads();
+        int *flag = reinterpret_cast<int *>(smem);                 // the operand tiles are dead here
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(p.sk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = (old == c_last - c_first) ? 1 : 0;
+            if (is_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.sk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            *flag = is_last;
+        }
+        __syncthreads();
+        if (*flag == 0) continue;                                  // somebody else finishes this tile
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        for (int c = c_first; c <= c_last; ++c) {                  // fixed order: the sum is independent of arrival order
+            const int cb = sk_begin_of(c);
+            const unsigned off = (unsigned)(2 * c + (max(cb, t_begin) == cb ? 0 : 1)) * SLAB + (unsigned)tid * 16u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsk, (int)off, ((i * TN + j) * 4 + e4) * NT * 16, 16);  // sc1: past this CU's L1
+                        const f32x4 f = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][e4 * 4 + e] += f[e];
+                    }
         }
     }
 
@@ -313,9 +409,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     // accumulator element e of lane l: column (n) = l & 31, row (m) = (e & 3) + 8*(e >> 2) + 4*(l >> 5).
     // Straight-line: out-of-tile elements get a voffset == num_records, which the buffer bounds check
     // turns into "load 0 / drop the store"; the 16 residual loads of a sub-tile are issued together.
-    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(p.residual ? p.residual : p.dst), 0, p.dst_bytes, 0x00020000);
     // interior tiles (the common case): one per-lane voffset per sub-tile, the row displacement of accumulator
     // element e rides in the scalar soffset -> no per-element address or bounds arithmetic on the VALU
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
@@ -369,6 +462,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     } else {
         if (p.leaky) emit(T_{}, F_{}); else emit(F_{}, F_{});
     }
+  } while (SK && (it += seg_k1 - seg_k0, first_segment = false, it < it_end));
 }
 
 // tile table: {BM, BN, waves, LDS stages}; ids are stable (tuning files refer to them)
@@ -382,20 +476,49 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {64, 128, 4, 1},                                     // probe 4
     {64, 128, 4, 2}, {64, 64, 4, 2}, {128, 128, 4, 2}, {128, 64, 4, 2}, {256, 32, 4, 2},  // 26..30: LDS-DMA loads
     {64, 128, 4, 1}, {64, 64, 4, 1},                     // 31, 32: LDS-DMA, single stage
+    // 33..40: stream-K schedule of tiles 10, 11, 9, 17, 26, 27, 31, 32
+    {64, 128, 4, 1, 1}, {64, 64, 4, 1, 1}, {128, 64, 4, 1, 1}, {128, 64, 8, 1, 1},
+    {64, 128, 4, 2, 1}, {64, 64, 4, 2, 1}, {64, 128, 4, 1, 1}, {64, 64, 4, 1, 1},
 };
 
 TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUNT) ? tile : 0]; }
 
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0>
-static hipError_t launch_k(const ConvArgs &a, hipStream_t s)
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0>
+static hipError_t launch_k(const ConvArgs &a_in, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
+    ConvArgs a = a_in;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
     const size_t lds = STAGES * (size_t)(BM + BN) * (DMA ? BK : LDS_ROW_PADDED) * sizeof(float);
-    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE, MINW, DMA>;
+    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE, MINW, DMA, SK>;
     static LdsAttrOnce attr;  // per instantiation
     if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
+    int grid = tilesM * tilesN;
+    if (SK) {
+        // as many workgroups as are resident at once (occupancy x CUs, per device), never more than there are iterations
+        static int resident[64] = {0};
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!resident[dev]) {
+            int occ = 0, cus = 0;
+            if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 64 * WR * WC, lds); e != hipSuccess) return e;
+            if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+            if (occ < 1 || cus < 1) return hipErrorInvalidValue;
+            resident[dev] = occ * cus;
+        }
+        const long long total = (long long)grid * (a.K / BK);
+        a.sk_tiles = grid;
+        int g = resident[dev];
+        if (a.sk_grid_override > 0) g = a.sk_grid_override;
+        if ((long long)g > total) g = (int)total;
+        const long long slab = (long long)BM * BN * 4;
+        if (!a.sk_ws || !a.sk_cnt || a.sk_tiles > a.sk_cnt_cap || total > 0x7fffffffLL) return hipErrorInvalidValue;
+        if (2LL * g * slab > (long long)a.sk_ws_bytes) g = (int)((long long)a.sk_ws_bytes / (2 * slab));
+        if (g < 1) return hipErrorInvalidValue;
+        grid = g;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }
 
@@ -436,6 +559,15 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 30: return a.src1 ? launch_k<2, 1, 4, 1, true, 2, 0, 1, 1>(a, s) : launch_k<2, 1, 4, 1, false, 2, 0, 1, 1>(a, s);  // 256x32
         case 31: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 1, 1>(a, s);  // 64x128, 1 stage
         case 32: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 1>(a, s);  // 64x64, 1 stage
+        // stream-K schedule (33..40 = tiles 10, 11, 9, 17, 26, 27, 31, 32)
+        case 33: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 4, 0, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 4, 0, 1>(a, s);
+        case 34: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 0, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 0, 1>(a, s);
+        case 35: return a.src1 ? launch_k<1, 2, 4, 1, true, 1, 0, 4, 0, 1>(a, s) : launch_k<1, 2, 4, 1, false, 1, 0, 4, 0, 1>(a, s);
+        case 36: return a.src1 ? launch_k<1, 1, 4, 2, true, 1, 0, 1, 0, 1>(a, s) : launch_k<1, 1, 4, 2, false, 1, 0, 1, 0, 1>(a, s);
+        case 37: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 0, 1, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 0, 1, 1, 1>(a, s);
+        case 38: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 0, 1, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 0, 1, 1, 1>(a, s);
+        case 39: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 1, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 1, 1, 1>(a, s);
+        case 40: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 1, 1>(a, s);
         case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 3>(a, s);
         case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 4>(a, s);
         default: return hipErrorInvalidValue;

@@ -30,6 +30,24 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+}  // namespace
+
+namespace y3 {
+// for the other translation units of the library (comm.cpp)
+int fail_msg(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace y3
+
+namespace {
+
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -92,6 +110,12 @@ struct y3_net {
     // y3_net_plan for max_batch images and Y3_MAX_OUTPUT_BOXES rows, so y3_net_detect itself only enqueues work
     void *det_buf = nullptr;
     size_t det_bytes = 0;
+    // stream-K conv tiles (fp32): partial-tile slabs + per-tile ticket counters, one region per lane
+    void *sk_ws = nullptr;
+    int *sk_cnt = nullptr;
+    size_t sk_ws_lane_bytes = 0;
+    int sk_cnt_cap = 0;
+    int sk_grid = 0;               // y3_net_set_sk_grid: > 0 overrides the number of persistent workgroups (tests)
     int cur_batch = 1;             // batch of the forward being enqueued
     hipEvent_t fork_ev = nullptr;
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -111,6 +135,12 @@ void free_plan(y3_net *n)
     if (n->det_buf) (void)hipFree(n->det_buf);
     n->det_buf = nullptr;
     n->det_bytes = 0;
+    if (n->sk_ws) (void)hipFree(n->sk_ws);
+    if (n->sk_cnt) (void)hipFree(n->sk_cnt);
+    n->sk_ws = nullptr;
+    n->sk_cnt = nullptr;
+    n->sk_ws_lane_bytes = 0;
+    n->sk_cnt_cap = 0;
     for (void *p : n->blocks) (void)hipFree(p);
     n->blocks.clear();
     n->tdev.assign(n->tensors.size(), nullptr);
@@ -513,6 +543,13 @@ y3_status y3_net_set_lanes(y3_net *net, int lanes)
     return Y3_OK;
 }
 
+y3_status y3_net_set_sk_grid(y3_net *net, int workgroups)
+{
+    if (!net || workgroups < 0) return fail(Y3_ERR_INVALID, "y3_net_set_sk_grid: bad argument");
+    net->sk_grid = workgroups;
+    return Y3_OK;
+}
+
 y3_status y3_net_set_early_chunk(y3_net *net, int n_convs, int chunk_images)
 {
     if (!net || n_convs < 0 || chunk_images < 0) return fail(Y3_ERR_INVALID, "y3_net_set_early_chunk: bad argument");
@@ -646,6 +683,25 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
         net->tblock[t] = pool[pick].bytes;
     }
     if (y3_status st = ensure_lanes(net); st != Y3_OK) return st;
+    if (dtype == Y3_DTYPE_F32) {
+        // stream-K workspace: 2 slabs per persistent workgroup (<= 2048 of them, <= 32 KB each) and one counter per
+        // output tile of the finest stream-K tile (64 x 64), per lane
+        net->sk_ws_lane_bytes = (size_t)2 * 2048 * 32768;
+        long long cap = 1;
+        for (const ConvSlot &c : net->convs) {
+            const long long sp = image_size / c.d.out_div;
+            const long long tiles = (((long long)max_batch * sp * sp + 63) / 64) * ((c.cout_pad + 63) / 64);
+            if (!c.first_layer && tiles > cap) cap = tiles;
+        }
+        net->sk_cnt_cap = (int)((cap + 3) & ~3LL);
+        hipError_t e = hipMalloc(&net->sk_ws, net->sk_ws_lane_bytes * Y3_MAX_LANES);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&net->sk_cnt), (size_t)net->sk_cnt_cap * 4 * Y3_MAX_LANES);
+        if (e == hipSuccess) e = hipMemset(net->sk_cnt, 0, (size_t)net->sk_cnt_cap * 4 * Y3_MAX_LANES);
+        if (e != hipSuccess) {
+            free_plan(net);
+            return fail(Y3_ERR_OOM, "y3_net_plan: stream-K workspace: %s", hipGetErrorString(e));
+        }
+    }
     if (net->nclasses > 0) {   // scratch of y3_net_detect: no allocation inside the stream-ordered call
         size_t off[9], n_boxes, gelems[3];
         int32_t gs[3];
@@ -769,6 +825,11 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.src1_bytes = d.src1 >= 0 ? (unsigned)bytes(d.src1) : 0;
             a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * sizeof(float));
             a.dst_bytes = (unsigned)bytes(d.dst);
+            a.sk_ws = net->sk_ws ? static_cast<char *>(net->sk_ws) + (size_t)lane * net->sk_ws_lane_bytes : nullptr;
+            a.sk_cnt = net->sk_cnt ? net->sk_cnt + (size_t)lane * net->sk_cnt_cap : nullptr;
+            a.sk_ws_bytes = (unsigned)net->sk_ws_lane_bytes;
+            a.sk_cnt_cap = net->sk_cnt_cap;
+            a.sk_grid_override = net->sk_grid;
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
             hipError_t e;
@@ -870,6 +931,9 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
     // Images are independent, so the batch can run as `lanes` sub-batches on forked streams: while one sub-batch's
     // conv kernel drains (its last workgroups leave CUs under-occupied), the other sub-batch's kernel fills them.
     net->cur_batch = batch;
+    // stream-K ticket counters: zeroed (synchronously) by y3_net_plan and returned to zero by the last contributor of
+    // every cut tile, so consecutive launches and forwards share the array without a per-forward memset (measured: a
+    // memset node in front of the kernels of a captured forward is not reliably ordered before them on replay)
     int lanes = (ms_out || net->lanes < 2) ? 1 : net->lanes;
     while (lanes > 1 && batch / lanes < 1) --lanes;
     // leading segment in chunks small enough for their activations to stay in the 256 MB Infinity Cache between the

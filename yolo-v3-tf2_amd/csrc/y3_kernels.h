@@ -26,6 +26,13 @@ struct ConvArgs {
     int M;                 // B*Ho*Wo
     int K;                 // ksize*ksize*Cin
     unsigned src0_bytes, src1_bytes, w_bytes, dst_bytes;
+    // stream-K schedule (fp32 tiles with TileInfo.sk): partial-tile slabs and per-tile ticket counters, owned by the net
+    void *sk_ws;           // >= 2 * workgroups * BM * BN * 4 bytes
+    int *sk_cnt;           // [sk_cnt_cap] zero between launches (the last contributor of a tile resets its counter)
+    unsigned sk_ws_bytes;
+    int sk_cnt_cap;
+    int sk_tiles;          // filled by the launcher: tilesM * tilesN
+    int sk_grid_override;  // > 0: number of workgroups instead of "everything resident at once" (tests)
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to the
@@ -43,8 +50,8 @@ inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes)
 }
 
 // tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
-static constexpr int TILE_COUNT = 33;  // 20..22 are timing-only probes
-struct TileInfo { int bm, bn, waves, stages; };
+static constexpr int TILE_COUNT = 41;  // 20..22, 25 are timing-only probes; 33..40 run the stream-K schedule
+struct TileInfo { int bm, bn, waves, stages; int sk = 0; };
 TileInfo conv_tile_info(int tile);
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);

@@ -39,6 +39,69 @@ def allgather_detections(packed: torch.Tensor, num_valid: torch.Tensor, group=No
     return out
 
 
+class Y3Comm:
+    """RCCL communicator behind the C ABI (y3_comm_* / y3_allgather_results in include/y3.h): the same exchange as
+    `allgather_detections`, but enqueued by liby3hip.so itself on the caller's stream -- one RCCL group per batch that
+    can sit in the same HIP graph as y3_net_detect, and that a non-Python host can call.
+
+    `Y3Comm.from_torch_distributed()` bootstraps from an initialised torch.distributed process group: rank 0 draws the
+    unique id and broadcasts it (128 bytes); the communicator itself is RCCL's own, not torch's.  One rank per GPU,
+    the current device is the rank's GPU."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int):
+        import ctypes as C
+        from . import _lib
+        _lib.require_gpu()
+        if len(unique_id) != _lib.Y3_COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        self.lib = _lib.load()
+        self.world, self.rank = int(world), int(rank)
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), _lib.Y3_COMM_ID_BYTES)
+        _lib.check(self.lib.y3_comm_init_rank(buf, self.world, self.rank, C.byref(self._h)), "y3_comm_init_rank")
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(_lib.Y3_COMM_ID_BYTES)
+        _lib.check(_lib.load().y3_comm_get_unique_id(buf), "y3_comm_get_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], world, rank)
+
+    def allgather(self, packed: torch.Tensor, num_valid: torch.Tensor,
+                  out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """packed [b,M,7] int32, num_valid [b] int32 on the GPU -> ([world*b,M,7], [world*b]) in rank order."""
+        import ctypes as C
+        from . import _lib
+        if not (packed.is_cuda and num_valid.is_cuda and packed.is_contiguous() and num_valid.is_contiguous()):
+            raise _lib.Y3Error("expected contiguous CUDA(HIP) tensors")
+        if packed.dtype != torch.int32 or num_valid.dtype != torch.int32 or packed.dim() != 3 or packed.shape[2] != 7:
+            raise _lib.Y3Error("packed must be int32 [b,M,7] and num_valid int32 [b]")
+        b, m = packed.shape[0], packed.shape[1]
+        if out is None:
+            out = (torch.empty((self.world * b, m, 7), dtype=torch.int32, device=packed.device),
+                   torch.empty((self.world * b,), dtype=torch.int32, device=packed.device))
+        _lib.check(self.lib.y3_allgather_results(self._h, C.c_void_p(packed.data_ptr()), C.c_void_p(num_valid.data_ptr()),
+                                                 b, m, C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
+                                                 _lib.stream_ptr()), "y3_allgather_results")
+        return out
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self.lib.y3_comm_destroy(h)
+            self._h = None
+
+    __del__ = close
+
+
 def allgather_ragged(packed: torch.Tensor, num_valid: torch.Tensor, n_images: int, group=None):
     """Uneven shards (n_images % world != 0): pad every rank's rows to the largest shard, gather, and drop
     the padding so that image order equals the un-sharded order."""

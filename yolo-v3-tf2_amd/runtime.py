@@ -101,22 +101,36 @@ class Net:
     def set_lanes(self, lanes: int):
         check(self.lib.y3_net_set_lanes(self._h, int(lanes)), "y3_net_set_lanes")
 
+    def set_sk_grid(self, workgroups: int):
+        """Number of persistent workgroups of the stream-K conv tiles (0 = everything resident at once)."""
+        check(self.lib.y3_net_set_sk_grid(self._h, int(workgroups)), "y3_net_set_sk_grid")
+
     def set_early_chunk(self, n_convs: int, chunk_images: int):
         """Before plan(): the first n_convs convs run chunk_images images at a time (their activations then stay in the
         Infinity Cache between producer and consumer); 0, 0 switches it off."""
         check(self.lib.y3_net_set_early_chunk(self._h, int(n_convs), int(chunk_images)), "y3_net_set_early_chunk")
 
+    # A tile forced through these setters survives plan(): the tuning table only fills the convs left on automatic
+    # (tile -1 hands the conv back to the table / the library's heuristic).
+    def _force(self, kind: str, fn, slot: int, tile: int):
+        check(fn(self._h, slot, tile), f"y3_net_set_tile{kind}")
+        forced = self.__dict__.setdefault("_forced_tiles", {})
+        if tile >= 0:
+            forced[(kind, slot)] = tile
+        else:
+            forced.pop((kind, slot), None)
+
     def set_tile(self, slot: int, tile: int):
-        check(self.lib.y3_net_set_tile(self._h, slot, tile), "y3_net_set_tile")
+        self._force("", self.lib.y3_net_set_tile, slot, tile)
 
     def set_tile_x3(self, slot: int, tile: int):
-        check(self.lib.y3_net_set_tile_x3(self._h, slot, tile), "y3_net_set_tile_x3")
+        self._force("_x3", self.lib.y3_net_set_tile_x3, slot, tile)
 
     def set_tile_x2(self, slot: int, tile: int):
-        check(self.lib.y3_net_set_tile_x2(self._h, slot, tile), "y3_net_set_tile_x2")
+        self._force("_x2", self.lib.y3_net_set_tile_x2, slot, tile)
 
     def set_tile_bf16(self, slot: int, tile: int):
-        check(self.lib.y3_net_set_tile_bf16(self._h, slot, tile), "y3_net_set_tile_bf16")
+        self._force("_bf16", self.lib.y3_net_set_tile_bf16, slot, tile)
 
     def plan(self, max_batch: int, image_size: int, dtype: Optional[int] = None):
         """dtype: _lib.Y3_DTYPE_F32 (default, fp32 MFMA), _lib.Y3_DTYPE_F32X3 (fp32-accurate on the bf16 matrix cores:
@@ -142,8 +156,10 @@ class Net:
         tag = _lib.DTYPE_TAGS[self.dtype]
         name = f"{tag}_b{self.max_batch}_s{self.image_size}.json"
         path = os.path.join(PACKAGE_DIR, "tuning", name)
-        setter = {_lib.Y3_DTYPE_F32: self.set_tile, _lib.Y3_DTYPE_BF16: self.set_tile_bf16,
-                  _lib.Y3_DTYPE_F32X3: self.set_tile_x3, _lib.Y3_DTYPE_F32X2: self.set_tile_x2}[self.dtype]
+        kind, fn = {_lib.Y3_DTYPE_F32: ("", self.lib.y3_net_set_tile), _lib.Y3_DTYPE_BF16: ("_bf16", self.lib.y3_net_set_tile_bf16),
+                    _lib.Y3_DTYPE_F32X3: ("_x3", self.lib.y3_net_set_tile_x3),
+                    _lib.Y3_DTYPE_F32X2: ("_x2", self.lib.y3_net_set_tile_x2)}[self.dtype]
+        forced = self.__dict__.get("_forced_tiles", {})
         table, lanes = {}, 1
         if os.path.exists(path) and not os.environ.get("Y3_NO_TUNING"):
             with open(path) as f:
@@ -152,9 +168,9 @@ class Net:
         # concurrent sub-batches (tools/lanes_sweep.py): the tail of one sub-batch's kernel overlaps another's bulk
         self.set_lanes(lanes)
         for slot, o in enumerate(self.conv_ops):
-            if o.cin == 3:
+            if o.cin == 3 or (kind, slot) in forced:
                 continue
-            setter(slot, int(table.get(self.conv_signature(o, self.image_size), -1)))
+            check(fn(self._h, slot, int(table.get(self.conv_signature(o, self.image_size), -1))), f"y3_net_set_tile{kind}")
 
     def grid_sizes(self, image_size=None):
         s = image_size or self.image_size
