@@ -61,6 +61,26 @@ def parity_gate(program, weights, anchors, images_host, device_out, n, M, iou, s
             "class_argmax_flips": flips}
 
 
+def host_cpu_share():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands one GPU's
+    share of a 256-thread host to the job; running 256 threads on it thrashes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except (OSError, ValueError):
+            pass
+    cap = os.environ.get("Y3_CPU_THREADS")
+    return max(1, min(n, int(cap))) if cap else n
+
+
 def cpu_baseline(program, weights, anchors, images_host, budget_s=20.0):
     """The reference's path on the host cores, on a bounded sample of the same batch (kind 'port': TensorFlow is not
     installed, so the reference itself cannot be timed).  Headline: the network on PyTorch-CPU operators (oneDNN
@@ -68,8 +88,7 @@ def cpu_baseline(program, weights, anchors, images_host, budget_s=20.0):
     Second field: the whole path through the oracle's naive C loops (what the parity tests compare against)."""
     import numpy as np
     import torch
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))   # before libgomp starts
+    cores = int(os.environ.get("OMP_NUM_THREADS", host_cpu_share()))   # fixed at start-up (main)
     torch.set_num_threads(cores)
     from oracle import oracle as O
     from oracle import torch_ref
@@ -126,6 +145,11 @@ def main():
     ap.add_argument("--per-layer", action="store_true", help="also print the per-conv timing table to stderr")
     args = ap.parse_args()
 
+    # host threads for the CPU legs (oracle parity gate, cpu_baseline): this process's real CPU share, fixed before any
+    # OpenMP runtime starts (torch's and the oracle's both read the environment once)
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cpu_share()))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner) write to fd 1 directly, so
     # fd 1 points at stderr until the line is printed
     sys.stdout.flush()
@@ -160,8 +184,9 @@ def main():
     net = runtime.Net(program)
     net.load_weights(weights)
     from yolo_v3_tf2_amd import _lib as y3lib
-    net.plan(B, S, {"f32": y3lib.Y3_DTYPE_F32, "f32x3": y3lib.Y3_DTYPE_F32X3, "f32x2": y3lib.Y3_DTYPE_F32X2,
-                    "bf16": y3lib.Y3_DTYPE_BF16}[args.dtype])
+    dt_ids = {"f32": y3lib.Y3_DTYPE_F32, "f32x3": y3lib.Y3_DTYPE_F32X3, "f32x2": y3lib.Y3_DTYPE_F32X2,
+              "bf16": y3lib.Y3_DTYPE_BF16}
+    net.plan(B, S, dt_ids[args.dtype])
     if args.lanes > 0:
         net.set_lanes(args.lanes)
     images_host = host_images(B, S, rank)
@@ -261,8 +286,9 @@ def main():
     mfma_flops_factor = {"f32x3": 6.0, "f32x2": 3.0}.get(args.dtype, 1.0)
 
     traffic = None
-    tf_path = os.path.join(ROOT, "profiles", f"r01_traffic_{args.dtype}_b{B}_s{S}.json")
-    if os.path.exists(tf_path):   # PMC-derived HBM bytes per conv-stack pass, measured by tools/profile.sh on this workload
+    tf_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic_{args.dtype}_b{B}_s{S}.json")
+                                for r in range(9, 0, -1)) if os.path.exists(q)), "")
+    if tf_path:   # PMC-derived HBM bytes per conv-stack pass, measured by tools/profile.sh on this workload (latest round)
         with open(tf_path) as f:
             traffic = json.load(f).get("conv_stack_hbm_bytes_per_step")
     # Extra information on the default (f32) line: the same workload in the fp32-accurate three-plane mode (bf16 matrix
@@ -339,6 +365,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(program, weights, anchors, images_host)
         if args.per_layer:
+            net.plan(B, S, dt_ids[args.dtype])       # the alt measurements re-planned the net: back to the headline mode
             ms = net.profile_convs(images)
             for o, t in zip(net.conv_ops, ms):
                 ho = S // o.out_div

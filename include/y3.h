@@ -121,6 +121,11 @@ y3_status y3_net_set_lanes(y3_net *net, int lanes);
  * last bits of an image's result may depend on the batch it is in -- the classic tiles 0..32 never split a sum).
  * y3_net_set_sk_grid: force the number of persistent workgroups (0 = everything resident at once); for tests. */
 y3_status y3_net_set_sk_grid(y3_net *net, int workgroups);
+/* Placement of the fp32 conv tiles on the 8 XCDs (each has a private 4 MB L2).  1 (default): per conv, the XCDs form an
+ * (8/gn) x gn grid over the (pixel-tile, channel-tile) matrix, gn chosen so that an XCD's slice of the weights stays in
+ * its L2 (the 256->512 / 512->1024 3x3 weights are 4.7 / 18.9 MB); 0: every XCD takes a contiguous run of tiles.
+ * Results are bit-identical in both modes (same per-tile arithmetic). */
+y3_status y3_net_set_xcd_mode(y3_net *net, int mode);
 y3_status y3_net_keep_activations(y3_net *net, int keep);
 /* Before y3_net_plan: run the first n_convs convs chunk_images images at a time, then the rest of the network on the
  * whole batch.  The first layers' activations are the largest tensors of the network (1.4 GB for 64 images at 416x416);

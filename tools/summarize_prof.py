@@ -13,11 +13,12 @@ def short(name):
     if m:
         tm, tn, wr, wc, cat, st = map(int, m.groups())
         return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{st}{',cat' if cat else ''}>"
-    m = re.search(r"conv_f32_mfma<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, (\d+), (\d+), (true|false|\d))?", name)
+    m = re.search(r"conv_f32_mfma<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, (\d+), (\d+), (true|false|\d))?(?:, (\d))?", name)
     if m:
         tm, tn, wr, wc = (int(m.group(i)) for i in range(1, 5))
         dma = ",dma" if m.group(9) in ("true", "1") else ""
-        return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{m.group(6)}{dma}{',cat' if m.group(5) == 'true' else ''}>"
+        sk = ",streamk" if m.group(10) == "1" else ""
+        return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{m.group(6)}{dma}{sk}{',cat' if m.group(5) == 'true' else ''}>"
     m = re.search(r"conv_bf16_mfma<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)", name)
     if m:
         tm, tn, wr, wc, bk = (int(m.group(i)) for i in range(1, 6))
@@ -51,16 +52,15 @@ def main(out):
     # PMC passes: sum counters per kernel name
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(int)
-    for p in sorted(glob.glob(os.path.join(out, "pmc*"))):
-        if not os.path.isdir(p):
-            continue
+    passes = [p for p in sorted(glob.glob(os.path.join(out, "pmc*"))) if os.path.isdir(p)]
+    for p in passes:
         seen = set()
         for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 key = (p, r["Dispatch_Id"])
-                if p.endswith("pmc1") and key not in seen:
+                if p == passes[0] and key not in seen:   # dispatch count from the first pass present
                     seen.add(key)
                     calls[k] += 1
     if agg:
@@ -80,14 +80,14 @@ def main(out):
             o.write("# derived: per kernel, all dispatches of the run\n")
             o.write(f"{'kernel':<52s} {'n':>4s} {'mfma_busy':>9s} {'waves/simd':>10s} {'fetchx2_MB/launch':>18s} "
                     f"{'write_MB/launch':>16s} {'l2_hit':>7s}\n")
-            for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0)):
+            for k in sorted(agg, key=lambda k: -(agg[k].get("SQ_WAVE_CYCLES", 0) or agg[k].get("FETCH_SIZE", 0))):
                 a = agg[k]
                 n = max(calls[k], 1)
                 cyc = a.get("GRBM_GUI_ACTIVE", 0) / 8.0
-                if cyc <= 0:
+                if cyc <= 0 and not (a.get("FETCH_SIZE") or a.get("WRITE_SIZE")):
                     continue
-                busy = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 1024)
-                occ = a.get("SQ_WAVE_CYCLES", 0) * 4 / (cyc * 1024)
+                busy = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 1024) if cyc > 0 else float("nan")
+                occ = a.get("SQ_WAVE_CYCLES", 0) * 4 / (cyc * 1024) if cyc > 0 else float("nan")
                 fetch = a.get("FETCH_SIZE", 0) * 1024 * 2 / n / 1e6
                 write = a.get("WRITE_SIZE", 0) * 1024 / n / 1e6
                 hm = a.get("TCC_HIT_sum", 0) + a.get("TCC_MISS_sum", 0)

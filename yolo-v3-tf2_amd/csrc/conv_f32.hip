@@ -16,6 +16,7 @@
 // contracted exactly once (the order of k inside a tile is irrelevant to the sum's value up to
 // fp32 rounding).
 // Epilogue from the accumulators: y = acc*scale[n] + shift[n]; leaky; + residual; store.
+#include <algorithm>
 #include <type_traits>
 
 #include "y3_kernels.h"
@@ -119,7 +120,23 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         seg_k1 = min(KT, seg_k0 + (it_end - it));
         if (!first_segment) __syncthreads();   // slower waves may still read the previous segment's LDS tiles / flag
     }
-    const int mt = tile / tilesN, nt = tile - mt * tilesN;
+    int mt = tile / tilesN, nt = tile - mt * tilesN;
+    if (!SK && p.xcd_gn > 0) {
+        // XCD-blocked order (launch_k sizes the grid for it): the 8 XCDs form a (8/gn) x gn grid over the tile matrix;
+        // XCD (xm, xn) owns M-tiles [xm*tilesM/gm, (xm+1)*tilesM/gm) x N-tiles [xn*tilesN/gn, +tilesN/gn), N fastest.
+        // With gn > 1 an XCD streams only 1/gn of the weight matrix through its 4 MB L2 (the 256->512 and 512->1024
+        // 3x3 weights are 4.7 / 18.9 MB) at the price of gn XCDs reading every activation tile.
+        const int gn = p.xcd_gn, gm = 8 / gn;
+        const int tilesM = (p.M + BM - 1) / BM;
+        const int xm = xcd / gn, xn = xcd - xm * gn;
+        const int nb = tilesN / gn;
+        const int mlo = xm * tilesM / gm, mhi = (xm + 1) * tilesM / gm;
+        const int j = bid >> 3;
+        const int lm = j / nb;
+        mt = mlo + lm;
+        nt = xn * nb + (j - lm * nb);
+        if (mt >= mhi) return;                 // padding workgroups of an uneven M split
+    }
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- per-thread gather state -------------------------------------------------------------
@@ -494,6 +511,13 @@ static hipError_t launch_k(const ConvArgs &a_in, hipStream_t s)
     static LdsAttrOnce attr;  // per instantiation
     if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
     int grid = tilesM * tilesN;
+    if (!SK && a.xcd_gn > 0) {
+        if (8 % a.xcd_gn || tilesN % a.xcd_gn) return hipErrorInvalidValue;
+        const int gm = 8 / a.xcd_gn;
+        int rows = 0;                                           // largest M block
+        for (int xm = 0; xm < gm; ++xm) rows = std::max(rows, (xm + 1) * tilesM / gm - xm * tilesM / gm);
+        grid = 8 * rows * (tilesN / a.xcd_gn);
+    }
     if (SK) {
         // as many workgroups as are resident at once (occupancy x CUs, per device), never more than there are iterations
         static int resident[64] = {0};

@@ -115,6 +115,7 @@ struct y3_net {
     int *sk_cnt = nullptr;
     size_t sk_ws_lane_bytes = 0;
     int sk_cnt_cap = 0;
+    int xcd_mode = 1;              // y3_net_set_xcd_mode: 0 contiguous tile runs per XCD, 1 XCD-blocked order chosen per conv
     int sk_grid = 0;               // y3_net_set_sk_grid: > 0 overrides the number of persistent workgroups (tests)
     int cur_batch = 1;             // batch of the forward being enqueued
     hipEvent_t fork_ev = nullptr;
@@ -266,6 +267,32 @@ int choose_tile_bf16(const ConvSlot &c, long long M)
         }
     }
     return best;
+}
+
+// How the 8 XCDs (each with its own 4 MB L2) divide the tile matrix of one fp32 conv launch: as a (8/gn) x gn grid of
+// blocks.  An XCD then streams 1/gn of the weights and 1/gm of the activations; the L2-miss traffic of the launch is
+// about gn * (activation bytes) + gm * (weight bytes), provided an XCD's weight slice stays L2-resident (<= 2.5 MB) while
+// its workgroups walk the K loop.  0 = not applicable (tile count too small / not divisible).
+int choose_xcd_gn(const ConvSlot &c, const y3::ConvArgs &a, const y3::TileInfo &t)
+{
+    if (t.sk) return 0;
+    const int tilesN = a.CoutPad / t.bn;
+    const long long tilesM = (a.M + t.bm - 1) / t.bm;
+    if (tilesM * tilesN < 64) return 0;
+    const double w_bytes = (double)a.CoutPad * c.K * 4.0, a_bytes = (double)a.src0_bytes + a.src1_bytes;
+    int best = 0;
+    double best_cost = 0;
+    for (int gn = 1; gn <= 8; gn *= 2) {
+        const int gm = 8 / gn;
+        if (tilesN % gn || tilesM < gm) continue;
+        double cost = gn * a_bytes + gm * w_bytes;
+        if (w_bytes / gn > 2.5e6) cost += 8.0 * (a_bytes + w_bytes);   // weight slice does not stay in L2: last resort
+        if (!best || cost < best_cost) {
+            best = gn;
+            best_cost = cost;
+        }
+    }
+    return best > 1 ? best : 0;   // gn = 1 is the contiguous order (8 pixel-tile runs), which needs no padding workgroups
 }
 
 int choose_tile(const ConvSlot &c, long long M)
@@ -540,6 +567,13 @@ y3_status y3_net_set_lanes(y3_net *net, int lanes)
 {
     if (!net || lanes < 1 || lanes > Y3_MAX_LANES) return fail(Y3_ERR_INVALID, "y3_net_set_lanes: lanes must be in [1,%d]", Y3_MAX_LANES);
     net->lanes = lanes;
+    return Y3_OK;
+}
+
+y3_status y3_net_set_xcd_mode(y3_net *net, int mode)
+{
+    if (!net || mode < 0 || mode > 1) return fail(Y3_ERR_INVALID, "y3_net_set_xcd_mode: mode must be 0 or 1");
+    net->xcd_mode = mode;
     return Y3_OK;
 }
 
@@ -830,6 +864,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.sk_ws_bytes = (unsigned)net->sk_ws_lane_bytes;
             a.sk_cnt_cap = net->sk_cnt_cap;
             a.sk_grid_override = net->sk_grid;
+            a.xcd_gn = 0;
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
             hipError_t e;
@@ -864,6 +899,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 e = y3::launch_conv_first_f32(a, c.w_dev, s);
             } else {
                 const int tile = c.tile >= 0 ? c.tile : choose_tile(c, a.M);
+                if (net->xcd_mode) a.xcd_gn = choose_xcd_gn(c, a, y3::conv_tile_info(tile));
                 e = y3::launch_conv_f32(a, tile, s);
             }
             if (e != hipSuccess) return fail(Y3_ERR_HIP, "conv %d launch: %s", o.index, hipGetErrorString(e));

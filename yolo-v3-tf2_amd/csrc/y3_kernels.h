@@ -33,6 +33,9 @@ struct ConvArgs {
     int sk_cnt_cap;
     int sk_tiles;          // filled by the launcher: tilesM * tilesN
     int sk_grid_override;  // > 0: number of workgroups instead of "everything resident at once" (tests)
+    // fp32 classic schedule: 0 = every XCD takes a contiguous run of tiles (N fastest); gn in {1,2,4,8} = the XCDs form
+    // an (8/gn) x gn grid over the (M-tile, N-tile) matrix (see conv_f32.hip)
+    int xcd_gn;
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to the

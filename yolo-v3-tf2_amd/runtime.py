@@ -101,6 +101,10 @@ class Net:
     def set_lanes(self, lanes: int):
         check(self.lib.y3_net_set_lanes(self._h, int(lanes)), "y3_net_set_lanes")
 
+    def set_xcd_mode(self, mode: int):
+        """fp32 conv tile placement on the 8 XCDs: 1 = XCD-blocked order chosen per conv (default), 0 = contiguous runs."""
+        check(self.lib.y3_net_set_xcd_mode(self._h, int(mode)), "y3_net_set_xcd_mode")
+
     def set_sk_grid(self, workgroups: int):
         """Number of persistent workgroups of the stream-K conv tiles (0 = everything resident at once)."""
         check(self.lib.y3_net_set_sk_grid(self._h, int(workgroups)), "y3_net_set_sk_grid")
