@@ -74,7 +74,7 @@ class Net:
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             self.lib.y3_net_destroy(h)
-            self._h = C.c_void_p()
+            self._h = None      # (module globals may already be gone at interpreter shutdown)
 
     # -- weights ----------------------------------------------------------------------------------
     def load_weights(self, weights: Dict[str, np.ndarray], eps: float = BN_EPS):
