@@ -186,6 +186,36 @@ def test_streamk_whole_network(rt, program, weights, anchors):
         assert all(torch.equal(a, b) for a, b in zip(got, outs)), [float((a - b).abs().max()) for a, b in zip(got, outs)]
 
 
+@pytest.mark.parametrize("tile", [41, 42, 43, 44, 45])
+def test_residual_prefetch_tiles_bit_identical(rt, tile):
+    """Tiles 41..45 request the shortcut operand one K iteration early; the arithmetic is that of the base tile, so the
+    results are bit-identical (residual convs), and convs without a shortcut simply run the base tile."""
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd._lib import RESPF_BASE, TILES
+    from oracle import oracle as O
+    cout = TILES[tile][1]
+    p = mini_program(cout, [dict(filters=cout // 2, size=1), dict(filters=cout, size=3, shortcut=-3),
+                            dict(filters=cout // 2, size=1), dict(filters=cout, size=3, shortcut=-3)],
+                     [dict(filters=cout, size=3), dict(filters=cout, size=1), dict(filters=cout, size=3, stride=2)])
+    w = synthetic_weights(p, seed=23)
+    x = np.random.default_rng(23).standard_normal((3, 22, 22, cout)).astype(np.float32)   # M = 1452: ragged tiles too
+    ref = O.forward(p, w, x)
+    outs = []
+    for t in (RESPF_BASE[tile], tile):
+        net = rt.Net(p)
+        net.load_weights(w)
+        for slot, o in enumerate(net.conv_ops):
+            if ((o.cout + 31) // 32 * 32) % cout == 0:
+                net.set_tile(slot, t)
+        net.plan(3, 22)
+        outs.append([g.clone() for g in net.forward(_cuda(x))])
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    for r, g in zip(ref, outs[1]):
+        assert np.abs(g.cpu().numpy().reshape(r.shape) - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
+
+
 def test_xcd_blocked_tile_order_is_bit_identical(rt):
     """Placement of the fp32 conv tiles on the 8 XCDs (y3_net_set_xcd_mode): the weight-heavy 3x3 convs take the
     XCD-blocked order (512->1024: 18.9 MB of weights -> every XCD one eighth of the channel tiles; 256->512 with 64x128

@@ -1,6 +1,9 @@
+#!/usr/bin/env python3
+"""A/B of the fp32 conv tile placement on the 8 XCDs (y3_net_set_xcd_mode 0 / 1): whole conv stack, alternating, and
+per conv (GPU).  Output kept as profiles/r02_xcd_order_ab_run*.txt."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import yolo_v3_tf2_amd
 from yolo_v3_tf2_amd import runtime as rt

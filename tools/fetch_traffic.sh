@@ -1,5 +1,6 @@
 #!/bin/bash
-# FETCH_SIZE / WRITE_SIZE passes only (HBM-side traffic per kernel), summarised like tools/profile.sh
+# FETCH_SIZE / WRITE_SIZE / L2 hit passes only (HBM-side traffic per kernel), summarised like tools/profile.sh.
+# usage: tools/fetch_traffic.sh <tag> [bench args...]  -> gpurun_out/prof_<tag>/summary_{derived.txt,traffic.json}
 tag=${1:-x}; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out

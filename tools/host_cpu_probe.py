@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""What the host side of a GPU box really offers: affinity, cgroup CPU quota, and PyTorch-CPU conv throughput versus
+thread count (output kept as profiles/r02_host_cpu_probe.txt)."""
 import os, time, torch, torch.nn.functional as F
 print("affinity", len(os.sched_getaffinity(0)), "cpu_count", os.cpu_count())
 for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):

@@ -1,6 +1,9 @@
+#!/usr/bin/env python3
+"""Debug aid for the stream-K tiles: a three-conv program, outputs pre-filled with NaN, compared row by row with the
+classic tile for a few workgroup counts (GPU).  Shows at once whether cut tiles are left unfinished or summed wrongly."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import yolo_v3_tf2_amd
 from yolo_v3_tf2_amd import runtime as rt

@@ -32,7 +32,10 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
          (64, 128, 4, 1), (64, 64, 4, 1),                   # 31, 32: LDS-DMA, single LDS stage
          # 33..40: the persistent stream-K schedule of tiles 10, 11, 9, 17, 26, 27, 31, 32
          (64, 128, 4, 1), (64, 64, 4, 1), (128, 64, 4, 1), (128, 64, 8, 1),
-         (64, 128, 4, 2), (64, 64, 4, 2), (64, 128, 4, 1), (64, 64, 4, 1)]
+         (64, 128, 4, 2), (64, 64, 4, 2), (64, 128, 4, 1), (64, 64, 4, 1),
+         # 41..45: residual prefetch variants of tiles 10, 31, 27, 11, 26 (identical results; other convs run the base tile)
+         (64, 128, 4, 1), (64, 128, 4, 1), (64, 64, 4, 2), (64, 64, 4, 1), (64, 128, 4, 2)]
+RESPF_BASE = {41: 10, 42: 31, 43: 27, 44: 11, 45: 26}
 SK_TILES = tuple(range(33, 41))
 SK_BASE = {33: 10, 34: 11, 35: 9, 36: 17, 37: 26, 38: 27, 39: 31, 40: 32}
 N_REAL_TILES = 20
@@ -57,7 +60,8 @@ TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4
               (128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (64, 128, 4, 64), (128, 256, 8, 64),  # 8..13: LDS-DMA loads
               (256, 256, 8, 64), (256, 128, 4, 64), (128, 256, 4, 64),  # 14..16: LDS-DMA, bigger wave tiles
               (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64)]  # 17..19: LDS-DMA, 16 waves
-TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if (26 <= i <= 32 or i >= 37) else "") + ("sk" if i >= 33 else "")
+TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if (26 <= i <= 32 or 37 <= i <= 40 or i in (42, 43, 45)) else "")
+              + ("sk" if 33 <= i <= 40 else "") + ("rp" if i >= 41 else "")
               for i, (bm, bn, w, st) in enumerate(TILES)]
 PROBE_TILES = (20, 21, 22, 25)  # timing-only ablations, wrong results
 

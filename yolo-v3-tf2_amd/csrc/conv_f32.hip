@@ -54,9 +54,12 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 // reads ALL slabs back (its own too) in contributor order -- so the sum does not depend on who arrives last -- and
 // runs the epilogue.  Nobody waits for anybody (no spinning, no residency assumption).  Protocol:
 // cdna_hip_programming.md section 5 (split-K slab reducer) / Guideline 16.
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0>
+// RESPF != 0 (tiles 41..45, convs with a shortcut operand only): the residual values of the tile are requested at the
+// top of the LAST K iteration instead of after it, so their latency runs under that iteration's 32 MFMAs per wave.
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0, int RESPF = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvArgs p)
 {
+    static_assert(!(RESPF && SK), "residual prefetch is built for the classic schedule only");
     constexpr int LDS_ROW = DMA ? BK : BK + 4;  // floats per LDS row
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
@@ -295,6 +298,34 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
     for (int q = 0; q < 4; ++q) foff[q] = DMA ? ((((2 * q + fh) ^ ((fr >> 1) & 7)) * 4)) : q * 8;
 
+    // epilogue geometry (needed early by the residual prefetch)
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
+    const int row_bytes = p.Cout * 4;
+    float rres[RESPF ? TM : 1][RESPF ? TN : 1][16];
+    auto load_res = [&]() {
+#pragma unroll
+        for (int j = 0; j < (RESPF ? TN : 0); ++j) {
+            const int n = n0 + (wc * TN + j) * 32 + fr;
+#pragma unroll
+            for (int i = 0; i < (RESPF ? TM : 0); ++i) {
+                const int mbase = m0 + (wr * TM + i) * 32 + 4 * fh;
+                const unsigned vbase = (unsigned)(mbase * p.Cout + n) * 4u;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dm = (e & 3) + 8 * (e >> 2);
+                    unsigned u;
+                    if (interior) {
+                        u = __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)vbase, dm * row_bytes, 0);
+                    } else {
+                        const unsigned off = (n < p.Cout && mbase + dm < p.M) ? (unsigned)((mbase + dm) * p.Cout + n) * 4u : p.dst_bytes;
+                        u = __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)off, 0, 0);
+                    }
+                    rres[i][j][e] = __builtin_bit_cast(float, u);
+                }
+            }
+        }
+    };
+
     f32x4 pfa[TM], pfb[TN];
     if (PROBE == 4) {
 #pragma unroll
@@ -304,6 +335,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     }
     for (int kt = seg_k0; kt < seg_k1; ++kt) {
         const int cur = (STAGES == 2) ? ((kt - seg_k0) & 1) : 0;
+        if (RESPF && kt == seg_k1 - 1) load_res();
         if (DMA && STAGES == 2) {
             if (kt + 1 < seg_k1) fetch_dma(cur ^ 1);   // every wave passed the barrier that ended tile kt-1: buf cur^1 is free
         } else if (DMA) {
@@ -428,8 +460,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     // turns into "load 0 / drop the store"; the 16 residual loads of a sub-tile are issued together.
     // interior tiles (the common case): one per-lane voffset per sub-tile, the row displacement of accumulator
     // element e rides in the scalar soffset -> no per-element address or bounds arithmetic on the VALU
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
-    const int row_bytes = p.Cout * 4;
     auto emit = [&](auto leaky_tag, auto res_tag) {
         constexpr bool LEAKY = decltype(leaky_tag)::value, RES = decltype(res_tag)::value;
 #pragma unroll
@@ -450,7 +480,10 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                     }
                 }
                 float r[16];
-                if (RES) {
+                if (RES && RESPF) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) r[e] = rres[RESPF ? i : 0][RESPF ? j : 0][e];
+                } else if (RES) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int so = ((e & 3) + 8 * (e >> 2)) * row_bytes;
@@ -474,7 +507,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    if (p.residual) {
+    if (RESPF) {                       // built for residual convs only (launch_conv_f32 guarantees p.residual)
+        if (p.leaky) emit(T_{}, T_{}); else emit(F_{}, T_{});
+    } else if (p.residual) {
         if (p.leaky) emit(T_{}, T_{}); else emit(F_{}, T_{});
     } else {
         if (p.leaky) emit(T_{}, F_{}); else emit(F_{}, F_{});
@@ -496,18 +531,20 @@ static const TileInfo kTiles[TILE_COUNT] = {
     // 33..40: stream-K schedule of tiles 10, 11, 9, 17, 26, 27, 31, 32
     {64, 128, 4, 1, 1}, {64, 64, 4, 1, 1}, {128, 64, 4, 1, 1}, {128, 64, 8, 1, 1},
     {64, 128, 4, 2, 1}, {64, 64, 4, 2, 1}, {64, 128, 4, 1, 1}, {64, 64, 4, 1, 1},
+    // 41..45: residual prefetch variants of tiles 10, 31, 27, 11, 26 (convs with a shortcut operand only)
+    {64, 128, 4, 1}, {64, 128, 4, 1}, {64, 64, 4, 2}, {64, 64, 4, 1}, {64, 128, 4, 2},
 };
 
 TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUNT) ? tile : 0]; }
 
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0>
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0, int RESPF = 0>
 static hipError_t launch_k(const ConvArgs &a_in, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     ConvArgs a = a_in;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
     const size_t lds = STAGES * (size_t)(BM + BN) * (DMA ? BK : LDS_ROW_PADDED) * sizeof(float);
-    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE, MINW, DMA, SK>;
+    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE, MINW, DMA, SK, RESPF>;
     static LdsAttrOnce attr;  // per instantiation
     if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
     int grid = tilesM * tilesN;
@@ -592,6 +629,12 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 38: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 0, 1, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 0, 1, 1, 1>(a, s);
         case 39: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 1, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 1, 1, 1>(a, s);
         case 40: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 1, 1>(a, s);
+        // residual prefetch (3x3 convs with a shortcut operand; anything else runs the base tile)
+        case 41: return (a.residual && !a.src1) ? launch_k<1, 2, 2, 2, false, 1, 0, 4, 0, 0, 1>(a, s) : launch_conv_f32(a, 10, s);
+        case 42: return (a.residual && !a.src1) ? launch_k<1, 2, 2, 2, false, 1, 0, 1, 1, 0, 1>(a, s) : launch_conv_f32(a, 31, s);
+        case 43: return (a.residual && !a.src1) ? launch_k<1, 1, 2, 2, false, 2, 0, 1, 1, 0, 1>(a, s) : launch_conv_f32(a, 27, s);
+        case 44: return (a.residual && !a.src1) ? launch_k<1, 1, 2, 2, false, 1, 0, 1, 0, 0, 1>(a, s) : launch_conv_f32(a, 11, s);
+        case 45: return (a.residual && !a.src1) ? launch_k<1, 2, 2, 2, false, 2, 0, 1, 1, 0, 1>(a, s) : launch_conv_f32(a, 26, s);
         case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 3>(a, s);
         case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 4>(a, s);
         default: return hipErrorInvalidValue;

@@ -53,7 +53,7 @@ inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes)
 }
 
 // tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
-static constexpr int TILE_COUNT = 41;  // 20..22, 25 are timing-only probes; 33..40 run the stream-K schedule
+static constexpr int TILE_COUNT = 46;  // 20..22, 25: timing-only probes; 33..40: stream-K schedule; 41..45: residual prefetch
 struct TileInfo { int bm, bn, waves, stages; int sk = 0; };
 TileInfo conv_tile_info(int tile);
 
