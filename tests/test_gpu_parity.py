@@ -498,7 +498,45 @@ def test_bf16_conv_layers_match_bf16_oracle(rt, case):
         assert np.abs(g - r).max() <= 2e-4 * max(1.0, float(np.abs(r).max())), (case, float(np.abs(g - r).max()))
 
 
-@pytest.mark.parametrize("tile", range(20))
+def test_bf16_pipelined_tile_repeatable_and_matches_oracle(rt):
+    """Tile 20 (256x256x64, DMA prefetch in flight across raw barriers, counted vmcnt): convs whose output stays bf16 --
+    3x3 (ragged M, image borders), 3x3 stride 2, 1x1 with K = 512, and a residual 3x3 -- against the bf16-emulating
+    oracle, and 30 repetitions bit-identical (a mis-placed wait shows up as rare wrong tiles, not as a steady error)."""
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    p = mini_program(128, [dict(filters=256, size=3), dict(filters=512, size=3, stride=2), dict(filters=256, size=1),
+                           dict(filters=512, size=3, shortcut=-3)],
+                     [dict(filters=64, size=1), dict(filters=64, size=1), dict(filters=64, size=1)])
+    w = synthetic_weights(p, seed=41)
+    B, S = 3, 26                                               # M = 2028 and 507: ragged 256-row tiles
+    x = O.round_bf16(np.random.default_rng(41).standard_normal((B, S, S, 128)).astype(np.float32))
+    ops = p.conv_ops()
+    keep = {o.dst for o in ops[:4]}
+    _, kept = O.forward(p, w, x, bf16=True, keep=keep)
+    net = rt.Net(p)
+    net.load_weights(w)
+    net.keep_activations(True)
+    for slot in range(4):
+        net.set_tile_bf16(slot, 20)
+    net.plan(B, S, _lib.Y3_DTYPE_BF16)
+    xd = _cuda(x).to(torch.bfloat16)
+    first = [g.clone() for g in net.forward(xd)]
+    for o in ops[:4]:
+        g = net.read_tensor(o.dst, B).cpu().numpy()
+        r = kept[o.dst]
+        bad = np.abs(g - r) > _bf16_ulp_elem(g, r) + 1e-5 * float(np.abs(r).max())
+        # free running over <= 4 layers: flipped roundings upstream move some values by more than an ulp (0.7 % of them
+        # at the fourth layer; the per-layer one-ulp bar on identical inputs is the teacher-forced test, which also
+        # runs this tile)
+        assert bad.mean() < 2e-2 and np.abs(g - r).max() <= 4 * 2.0 ** -8 * float(np.abs(r).max()), (o.conv_index, float(bad.mean()))
+    for _ in range(30):
+        again = net.forward(xd)
+        assert all(torch.equal(a, b) for a, b in zip(first, again))
+
+
+@pytest.mark.parametrize("tile", range(21))
 def test_bf16_every_tile(rt, tile):
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
@@ -580,7 +618,8 @@ def test_bf16_network_deviation_is_reported(rt, program, weights, anchors):
     assert rel32 < 3e-2 and d32 < 0.5          # bf16 quantisation through 75 layers
 
 
-def test_bf16_every_layer_teacher_forced_within_one_ulp(rt, program, weights):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_bf16_every_layer_teacher_forced_within_one_ulp(rt, program, weights, pipelined):
     """Kernel-correctness bar of the bf16 path, layer by layer on the real network: every fused launch is recomputed by
     the oracle FROM THE DEVICE'S OWN INPUT TENSORS (bf16 values are exact in fp32), rounded where the kernel rounds,
     and compared with the device's output: every element within one bf16 ulp (+ 1e-5 of the layer's magnitude for values
@@ -594,6 +633,10 @@ def test_bf16_every_layer_teacher_forced_within_one_ulp(rt, program, weights):
     net = rt.Net(program)
     net.load_weights(weights)
     net.keep_activations(True)
+    if pipelined:     # tile 20 (pipelined K loop) wherever it applies; the launcher runs tile 17 on the other convs
+        for slot, o in enumerate(net.conv_ops):
+            if o.cin % 64 == 0 and o.cout % 256 == 0:
+                net.set_tile_bf16(slot, 20)
     net.plan(B, S, _lib.Y3_DTYPE_BF16)
     grids = net.forward(_cuda(x))
     torch.cuda.synchronize()

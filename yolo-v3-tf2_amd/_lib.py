@@ -59,7 +59,8 @@ TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4
               (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64),
               (128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (64, 128, 4, 64), (128, 256, 8, 64),  # 8..13: LDS-DMA loads
               (256, 256, 8, 64), (256, 128, 4, 64), (128, 256, 4, 64),  # 14..16: LDS-DMA, bigger wave tiles
-              (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64)]  # 17..19: LDS-DMA, 16 waves
+              (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64),  # 17..19: LDS-DMA, 16 waves
+              (256, 256, 8, 64)]  # 20: pipelined K loop (prefetch in flight across raw barriers, counted vmcnt)
 TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if (26 <= i <= 32 or 37 <= i <= 40 or i in (42, 43, 45)) else "")
               + ("sk" if 33 <= i <= 40 else "") + ("rp" if i >= 41 else "")
               for i, (bm, bn, w, st) in enumerate(TILES)]

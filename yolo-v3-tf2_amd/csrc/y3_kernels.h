@@ -62,7 +62,7 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
 hipError_t launch_conv_first_f32(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
 
 // bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
-static constexpr int BF16_TILE_COUNT = 20;
+static constexpr int BF16_TILE_COUNT = 21;
 TileInfo conv_bf16_tile_info(int tile);
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);
 hipError_t launch_conv_first_bf16(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
