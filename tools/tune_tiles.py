@@ -49,7 +49,7 @@ def main():
                     "f32x2": _lib.Y3_DTYPE_F32X2}[a.dtype])
     x = torch.rand((B, S, S, 3), device="cuda")
     TL = _lib.TILES_X3 if x3 else _lib.TILES_BF16 if bf else TILES
-    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if (i >= 8 and not x3) else "") + ("s1" if (x3 and i in (9, 10, 11, 13, 14, 15)) else "") + ("i" if (x3 and 20 <= i < 26) else "") + ("p" if (x3 and i in (28, 29)) else "") + ("s3" if (x3 and 30 <= i < 34) else "") + ("sk" if (x3 and 34 <= i < 37) else "") + ("nold" if (x3 and 37 <= i < 40) else "") + ("ld" if (x3 and 40 <= i < 43) else "") + ("a1" if (x3 and i >= 43) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
+    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("pipe" if (i == 20 and not x3) else "d" if (i >= 8 and not x3) else "") + ("s1" if (x3 and i in (9, 10, 11, 13, 14, 15)) else "") + ("i" if (x3 and 20 <= i < 26) else "") + ("p" if (x3 and i in (28, 29)) else "") + ("s3" if (x3 and 30 <= i < 34) else "") + ("sk" if (x3 and 34 <= i < 37) else "") + ("nold" if (x3 and 37 <= i < 40) else "") + ("ld" if (x3 and 40 <= i < 43) else "") + ("a1" if (x3 and i >= 43) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
     tiles = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else list(range(len(TL)))
     if a.tiles == "all":   # timing-only probe tiles (wrong results) must be asked for by id; never with --write
         probes = _lib.PROBE_TILES_X2 if x2 else () if bf else _lib.PROBE_TILES
