@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""A/B of two builds of liby3hip.so on ONE box: alternating child processes (Y3_LIB_PATH), each timing the conv stack of
+the headline workload.  Boxes differ by +-2.5 %, processes on one box by < 0.5 %.
+   python tools/ab_libs.py yolo-v3-tf2_amd/lib/liby3hip.so yolo-v3-tf2_amd/lib/liby3hip_var.so [--dtype f32] [--rounds 3]"""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import yolo_v3_tf2_amd
+from yolo_v3_tf2_amd import runtime, _lib
+from yolo_v3_tf2_amd.graph import load_program
+from yolo_v3_tf2_amd.weights import synthetic_weights
+p = load_program(os.path.join(%r, "config/models/yolov3/model.yaml"), 80)
+net = runtime.Net(p); net.load_weights(synthetic_weights(p))
+B, S, dt = %d, %d, %r
+net.plan(B, S, {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x2": _lib.Y3_DTYPE_F32X2, "f32x3": _lib.Y3_DTYPE_F32X3}[dt])
+x = torch.rand((B, S, S, 3), device="cuda")
+g = [torch.empty((B, s, s, 3, 85), device="cuda") for s in net.grid_sizes()]
+for _ in range(5): net.forward(x, out=g)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
+for _ in range(30): net.forward(x, out=g)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 30
+print("RESULT %%.4f %%.2f" %% (ms, net.flops_per_image() * B / ms / 1e9), flush=True)
+'''
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--image-size", type=int, default=416)
+    ap.add_argument("--rounds", type=int, default=3)
+    a = ap.parse_args()
+    code = CHILD % (ROOT, ROOT, a.batch, a.image_size, a.dtype)
+    res = {lib: [] for lib in a.libs}
+    for r in range(a.rounds):
+        for lib in a.libs:
+            env = dict(os.environ, Y3_LIB_PATH=os.path.abspath(lib))
+            out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+            line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+            if not line:
+                print(out.stdout[-500:], out.stderr[-1500:])
+                sys.exit(1)
+            ms, tf = line[0].split()[1:]
+            res[lib].append(float(ms))
+            print(f"round {r} {os.path.basename(lib):28s} conv stack {ms} ms  {tf} TF/s", flush=True)
+    for lib, v in res.items():
+        print(f"{os.path.basename(lib):28s} min {min(v):.3f} ms  mean {sum(v) / len(v):.3f} ms")
+
+
+if __name__ == "__main__":
+    main()

@@ -11,7 +11,8 @@ import os
 
 from . import PACKAGE_DIR
 
-LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "liby3hip.so")
+# Y3_LIB_PATH: load another build of the same ABI (A/B of kernel variants on one box: tools/ab_libs.py)
+LIB_PATH = os.environ.get("Y3_LIB_PATH") or os.path.join(PACKAGE_DIR, "lib", "liby3hip.so")
 
 Y3_OK = 0
 Y3_DTYPE_F32, Y3_DTYPE_BF16, Y3_DTYPE_F32X3, Y3_DTYPE_F32X2 = 0, 1, 2, 3

@@ -13,7 +13,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-Wall", "-Wno-unused-function"]
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), out=None, only=None):
+    """defines / out / only: build a variant of the library (extra -D flags, other output name, subset of sources
+    recompiled with the flags; the other objects are shared with the default build) for tools/ab_libs.py."""
+    if defines or out:
+        return _build_variant(list(defines), out or OUT.replace(".so", "_var.so"), only or SOURCES, verbose)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -43,5 +47,30 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def _build_variant(defines, out, only, verbose):
+    build()                                   # default objects first
+    objdir = os.path.join(HERE, "build")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tag = "_".join(d.replace("=", "") for d in defines) or "var"
+    objs = []
+    for src in SOURCES:
+        if src in only:
+            obj = os.path.join(objdir, f"{src}.{tag}.o")
+            cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        else:
+            obj = os.path.join(objdir, src + ".o")
+        objs.append(obj)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"])
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:                # build.py --variant OUT.so SRC.hip -DNAME[=V] ...
+        i = sys.argv.index("--variant")
+        out_, src_ = sys.argv[i + 1], sys.argv[i + 2]
+        print(build(defines=[a[2:] for a in sys.argv[i + 3:] if a.startswith("-D")], out=os.path.abspath(out_), only=[src_], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -365,6 +365,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+            // (s_setprio 1 / 0 around this block: -0.6 % on the conv stack, tools/ab_libs.py, round 2)
         }
         if (DMA && STAGES == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 has landed (issued a whole K tile ago)
