@@ -12,8 +12,8 @@ has `max_output_size` survivors) follows TF op by op so that its quirks are visi
     i.e. it can stop one round early if a round removes total IoU mass <= threshold
     (only possible when a single pair with IoU == threshold, up to fp32 summation error,
     is removed in the final round).  oracle/y3_oracle.c and the HIP kernel compute the
-    converged fixed point (= plain greedy NMS); tests/test_nms_oracle.py checks both agree
-    on the stress sets and documents this corner as the one known divergence.
+    converged fixed point (= plain greedy NMS); tests/test_oracle.py (the `tiled` tests) checks that both
+    agree on the stress sets and documents this corner as the one known divergence.
 
 Slow (seconds per image at N=10647); used for cross-validation at small/medium sizes.
 """
