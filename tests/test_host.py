@@ -116,3 +116,21 @@ def test_evaluate_detections_counters():
     assert abs(r - 2 / 3) < 1e-9 and abs(p_ - 0.5) < 1e-9
     b, cl, s_ = EvaluateDetections.gather_nms_output(pr_b, pr_c, np.arange(4.0), np.array([3, 1, 0, 0]), 2)
     assert cl.tolist() == [2, 0] and s_.tolist() == [3.0, 1.0]
+
+
+def test_bench_host_helpers(monkeypatch):
+    """bench.py's host-side pieces that need no GPU: the seeded batch every leg shares, and the CPU share used for the
+    oracle / PyTorch-CPU legs (affinity capped by the cgroup quota, overridable)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("y3_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a, b = bench.host_images(2, 32, 0), bench.host_images(2, 32, 0)
+    assert a.shape == (2, 32, 32, 3) and a.dtype.name == "float32" and (a == b).all() and 0.0 <= a.min() and a.max() < 1.0
+    assert not (bench.host_images(2, 32, 1) == a).all()          # every rank draws its own images
+    n = bench.host_cpu_share()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    monkeypatch.setenv("Y3_CPU_THREADS", "1")
+    assert bench.host_cpu_share() == 1
