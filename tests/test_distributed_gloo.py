@@ -90,3 +90,54 @@ def test_sharded_detect_equals_single_process(n_images):
     pb, ps, pc, pi = unpack_detections(torch.from_numpy(g))
     n0 = int(gn[0])
     assert torch.equal(pi[0, :n0], torch.from_numpy(ref[0, :n0, 6])) and pb.shape == (n_images, 100, 4)
+
+
+def _comm_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["Y3_RCCL_LIB"] = "/nonexistent/librccl.so.0"     # rank 0 cannot draw an id
+    import yolo_v3_tf2_amd  # noqa: F401
+    from yolo_v3_tf2_amd import _lib
+    from yolo_v3_tf2_amd.parallel import Y3Comm
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Y3Comm.from_torch_distributed()
+        out = "no error"
+    except _lib.Y3Error as e:
+        out = str(e)
+    # the ranks are still in step: a collective issued after the failure completes on both
+    t = torch.tensor([rank + 1])
+    dist.all_reduce(t)
+    q.put((rank, out, int(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_bootstrap_failure_raises_on_every_rank():
+    """Y3Comm.from_torch_distributed with rank 0 unable to draw the RCCL id: every rank raises the same Y3Error and
+    nobody is left inside the broadcast (rank 0 used to raise before entering it)."""
+    ctx = mp.get_context("spawn")
+    res = None
+    for attempt in range(2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            res = sorted(q.get(timeout=120) for _ in range(2))
+        except Exception:
+            res = None
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if res is not None and all(p.exitcode == 0 for p in procs):
+            break
+    assert res is not None, "gloo workers failed twice"
+    assert [r[0] for r in res] == [0, 1]
+    for _, msg, total in res:
+        assert "rank 0 could not draw an RCCL unique id" in msg and "librccl not found" in msg, msg
+        assert total == 3

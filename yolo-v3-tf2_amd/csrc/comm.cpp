@@ -12,6 +12,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -42,13 +43,20 @@ Rccl &rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         // an instance already mapped into the process first (RTLD_NOLOAD), then the system one
+        // Y3_RCCL_LIB names the library instead (tests use it to force the not-found path)
         const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names)
-            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        for (const char *n : names)
-            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        const char *forced = getenv("Y3_RCCL_LIB");
+        if (forced && forced[0]) {
+            r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *n : names)
+                if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            for (const char *n : names)
+                if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
         if (!r.handle) {
-            r.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+            const char *m = dlerror();   // one call: dlerror() clears the message it returns
+            r.error = std::string("librccl not found: ") + (m ? m : "?");
             return;
         }
         auto sym = [&](const char *name) {

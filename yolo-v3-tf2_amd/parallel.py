@@ -70,10 +70,38 @@ class Y3Comm:
 
     @classmethod
     def from_torch_distributed(cls, group=None):
+        """Every rank enters the same two collectives whatever happens on any of them: rank 0 broadcasts either the id
+        or the error it hit drawing it, and after ncclCommInitRank the ranks agree (all-reduce of a flag) that every
+        one of them holds a communicator -- so a failure raises the same exception everywhere instead of leaving some
+        ranks inside a collective the others never join."""
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        box = [cls.new_unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = ("id", cls.new_unique_id())
+            except Exception as e:   # noqa: BLE001 - forwarded to every rank below
+                box[0] = ("err", f"{type(e).__name__}: {e}")
         dist.broadcast_object_list(box, src=0, group=group)
-        return cls(box[0], world, rank)
+        kind, payload = box[0]
+        if kind != "id":
+            from . import _lib
+            raise _lib.Y3Error(f"rank 0 could not draw an RCCL unique id: {payload}")
+        comm, err = None, ""
+        try:
+            comm = cls(payload, world, rank)
+        except Exception as e:   # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        backend = dist.get_backend(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        bad = torch.tensor([0 if comm is not None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(bad, group=group)
+        if int(bad.item()):
+            if comm is not None:
+                comm.close()
+            from . import _lib
+            raise _lib.Y3Error(f"y3_comm_init_rank failed on {int(bad.item())} of {world} ranks"
+                               + (f" (this rank: {err})" if err else ""))
+        return comm
 
     def allgather(self, packed: torch.Tensor, num_valid: torch.Tensor,
                   out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
