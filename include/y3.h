@@ -45,6 +45,11 @@ int y3_version(void);
 const char *y3_last_error(void);
 /* number of visible HIP devices (0 when none); never fails */
 int y3_device_count(void);
+/* 1 when tile id `tile` of the conv kernel family of `dtype` (Y3_DTYPE_*) is compiled into this library, else 0.
+ * The default build carries the tiles a tuning table or heuristic can select; timing-only probes, the stream-K
+ * schedule (fp32 33..40), the residual-prefetch variants (fp32 41..45) and the pipelined bf16 tile (20) were measured
+ * and lost and exist only in libraries built with csrc/build.py --experimental. */
+int y3_tile_built(int dtype, int tile);
 
 /* ------------------------------------------------------------------------------------------
  * Network = the fused conv program.
@@ -115,7 +120,7 @@ y3_status y3_net_set_tile_x2(y3_net *net, int conv_slot, int tile);   /* same ti
  * stream: the tail of one sub-batch's conv kernel overlaps the next kernel of another.  Results are unchanged
  * (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
 y3_status y3_net_set_lanes(y3_net *net, int lanes);
-/* fp32 tiles 33..40 run the persistent "stream-K" schedule: as many workgroups as the chip holds at once, each with an
+/* (experimental builds only, see y3_tile_built) fp32 tiles 33..40 run the persistent "stream-K" schedule: as many workgroups as the chip holds at once, each with an
  * equal share of the (tile, K-tile) iterations; tiles cut between workgroups are summed through fp32 slabs in a
  * net-owned workspace in a fixed order (run-to-run deterministic; the split points depend on the launch geometry, so the
  * last bits of an image's result may depend on the batch it is in -- the classic tiles 0..32 never split a sum).

@@ -89,3 +89,25 @@ class TorchNet:
 
 def forward(model_config_file, weights, images, nclasses, **kw):
     return TorchNet(model_config_file, weights, nclasses, **kw)(images)
+
+
+def detect(program, weights, images, anchors_table, yolo_max_boxes=100, nms_iou_threshold=0.5,
+           nms_score_threshold=0.1):
+    """The reference's 5-tuple with the network on PyTorch-CPU operators and the oracle's C decode / score / NMS: the
+    second, independent fp32 CPU implementation next to oracle.detect (same inputs, different summation order inside
+    the convolutions).  The deviation between the two is the floor any third implementation is measured against."""
+    from . import oracle as O
+    grids = TorchNet(program.model_config_file, weights, program.nclasses)(images)
+    return O.yolo_nms(O.yolo_decode(grids, anchors_table, program.nclasses), yolo_max_boxes, nms_iou_threshold,
+                      nms_score_threshold)
+
+
+def box_deviation(got_boxes, ref_boxes, got_scores, ref_scores):
+    """The numbers every parity report quotes, for any pair of runs: raw, inside the unit range, scaled."""
+    err = np.abs(got_boxes - ref_boxes)
+    unit = np.abs(ref_boxes) <= 1.0
+    return {"max_abs_dbox_raw": float(err.max()),
+            "max_abs_dbox_coords_within_unit_range": float(err[unit].max()) if unit.any() else 0.0,
+            "max_dbox_over_max1_abs_coord": float((err / np.maximum(1.0, np.abs(ref_boxes))).max()),
+            "largest_abs_box_coord": float(np.abs(ref_boxes).max()),
+            "max_abs_dscore": float(np.abs(got_scores - ref_scores).max())}

@@ -88,3 +88,31 @@ def test_rccl_not_loadable_is_a_status_not_a_crash():
     env = dict(os.environ, Y3_RCCL_LIB="/nonexistent/librccl.so.0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_tile_built_reports_the_default_tile_set():
+    """y3_tile_built (no GPU needed): the default library holds exactly the tiles a tuning table or heuristic can pick;
+    probes, stream-K, residual prefetch and the pipelined bf16 tile exist only in csrc/build.py --experimental."""
+    from yolo_v3_tf2_amd import _lib
+    exp = _lib.tile_built(_lib.Y3_DTYPE_F32, 33)
+    f32 = [t for t in range(len(_lib.TILES)) if _lib.tile_built(_lib.Y3_DTYPE_F32, t)]
+    bf16 = [t for t in range(len(_lib.TILES_BF16)) if _lib.tile_built(_lib.Y3_DTYPE_BF16, t)]
+    x2 = [t for t in range(len(_lib.TILES_X3)) if _lib.tile_built(_lib.Y3_DTYPE_F32X2, t)]
+    x3 = [t for t in range(len(_lib.TILES_X3)) if _lib.tile_built(_lib.Y3_DTYPE_F32X3, t)]
+    assert not _lib.tile_built(_lib.Y3_DTYPE_F32, -1) and not _lib.tile_built(_lib.Y3_DTYPE_F32, len(_lib.TILES))
+    assert not _lib.tile_built(7, 0)
+    assert x3 == list(_lib.TILES_X3_BUILT)
+    if exp:
+        assert f32 == list(range(len(_lib.TILES))) and bf16 == list(range(21))
+        assert x2 == sorted(_lib.TILES_X2_BUILT + _lib.PROBE_TILES_X2)
+    else:
+        assert f32 == list(range(20)) + [23, 24] + list(range(26, 33)) and bf16 == list(range(20))
+        assert x2 == list(_lib.TILES_X2_BUILT)
+    # every tile a committed tuning table names is in the default set
+    import glob
+    import json
+    for f in glob.glob(os.path.join(ROOT, "yolo-v3-tf2_amd", "tuning", "*.json")):
+        tag = os.path.basename(f).split("_")[0]
+        dt = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3, "f32x2": _lib.Y3_DTYPE_F32X2}[tag]
+        for sig, t in json.load(open(f))["tiles"].items():
+            assert t < 0 or _lib.tile_built(dt, t), (f, sig, t)

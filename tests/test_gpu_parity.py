@@ -26,11 +26,41 @@ def _cuda(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def _need_tile(dtype_tag, tile):
+    """Experimental tiles (timing probes, stream-K, residual prefetch, pipelined bf16) are left out of the default
+    library (y3_tile_built): their tests run against csrc/build.py --experimental via Y3_LIB_PATH, and skip otherwise."""
+    from yolo_v3_tf2_amd import _lib
+    dt = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3, "f32x2": _lib.Y3_DTYPE_F32X2}[dtype_tag]
+    if not _lib.tile_built(dt, tile):
+        pytest.skip(f"{dtype_tag} tile {tile} is an experimental tile: build csrc/build.py --experimental and set Y3_LIB_PATH")
+
+
 def _boxes_close(got, ref):
-    """north_star's 1e-4 on box coordinates, as stated for normalised boxes: absolute inside the unit range, relative
-    for the (unclipped, random-init) boxes that are many image widths wide -- w = exp(tw) * anchor turns a 1e-5
-    summation-order difference in tw into 1e-5 * w."""
-    return float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max()) <= 1e-4
+    """north_star's 1e-4 on box coordinates: strictly absolute wherever |coord| <= 1 (where detections live), relative
+    to |coord| for the unclipped random-init boxes many image widths wide (w = exp(tw) * anchor turns a 1e-5
+    summation-order difference in tw into 1e-5 * w).  tests/test_oracle.py::
+    test_two_cpu_fp32_implementations_bound_the_box_bar shows two CPU fp32 implementations already miss an absolute
+    1e-4 on those wide boxes (5e-4 on girl.png) while meeting both parts of this bar."""
+    err = np.abs(got - ref)
+    unit = np.abs(ref) <= 1.0
+    strict = (not unit.any()) or float(err[unit].max()) <= 1e-4
+    return strict and float((err / np.maximum(1.0, np.abs(ref))).max()) <= 1e-4
+
+
+def _selection_explained(ref5, dev5, iou=0.5, score=0.1):
+    """End-to-end selections equal, or every difference attributed to a near-tie (oracle/flip_attribution.py) whose
+    margin the measured box / score deviation covers.  Returns the flips (reported by the caller, never hidden)."""
+    from oracle import flip_attribution as FA
+    rb, _, rs, rsel, rnv = ref5
+    gb, _, gs, gsel, gnv = dev5
+    flips = FA.attribute(rb, rs, rsel, rnv, gb, gs, gsel, gnv, iou, score)
+    err = np.abs(gb - rb)
+    unit = np.abs(rb) <= 1.0
+    dbox = float(err[unit].max()) if unit.any() else 0.0
+    assert FA.explained(flips, float(np.abs(gs - rs).max()), dbox), f"selection differs without a near-tie: {flips}"
+    if flips:
+        print("selection flips (near-ties):", flips)
+    return flips
 
 
 # ---------------------------------------------------------------------------------------------- conv
@@ -78,6 +108,7 @@ def _real_tiles():
 @pytest.mark.parametrize("tile", _real_tiles())
 def test_conv_every_tile_shape(rt, tile):
     """Force each block tile of the MFMA kernel on a shape with ragged M (M % BM != 0)."""
+    _need_tile("f32", tile)
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
     from yolo_v3_tf2_amd._lib import TILES
@@ -106,6 +137,7 @@ def test_streamk_tiles_any_workgroup_count(rt, tile):
     cut a tile in 2, in many pieces (a share shorter than one tile), uneven remainders, and the default 'everything
     resident' -- the result matches the oracle, is bit-identical run to run, and with G = 1 (nothing is cut) it is
     bit-identical to the classic schedule of the same block tile."""
+    _need_tile("f32", tile)
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
     from yolo_v3_tf2_amd._lib import SK_BASE, TILES
@@ -145,6 +177,7 @@ def test_streamk_whole_network(rt, program, weights, anchors):
     """Every MFMA conv of the network on a stream-K tile: head grids within 1e-4 of the oracle, boxes / scores within
     the bar, NMS bit-exact on the device's boxes, deterministic, and identical when replayed from a HIP graph (the
     ticket counters return to zero by themselves: every cut tile's last contributor resets its counter)."""
+    _need_tile("f32", 33)
     from yolo_v3_tf2_amd._lib import TILES
     from oracle import oracle as O
     S, B = 96, 3
@@ -190,6 +223,7 @@ def test_streamk_whole_network(rt, program, weights, anchors):
 def test_residual_prefetch_tiles_bit_identical(rt, tile):
     """Tiles 41..45 request the shortcut operand one K iteration early; the arithmetic is that of the base tile, so the
     results are bit-identical (residual convs), and convs without a shortcut simply run the base tile."""
+    _need_tile("f32", tile)
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
     from yolo_v3_tf2_amd._lib import RESPF_BASE, TILES
@@ -502,6 +536,7 @@ def test_bf16_pipelined_tile_repeatable_and_matches_oracle(rt):
     """Tile 20 (256x256x64, DMA prefetch in flight across raw barriers, counted vmcnt): convs whose output stays bf16 --
     3x3 (ragged M, image borders), 3x3 stride 2, 1x1 with K = 512, and a residual 3x3 -- against the bf16-emulating
     oracle, and 30 repetitions bit-identical (a mis-placed wait shows up as rare wrong tiles, not as a steady error)."""
+    _need_tile("bf16", 20)
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
     from yolo_v3_tf2_amd import _lib
@@ -538,6 +573,7 @@ def test_bf16_pipelined_tile_repeatable_and_matches_oracle(rt):
 
 @pytest.mark.parametrize("tile", range(21))
 def test_bf16_every_tile(rt, tile):
+    _need_tile("bf16", tile)
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
     from yolo_v3_tf2_amd import _lib
@@ -626,6 +662,8 @@ def test_bf16_every_layer_teacher_forced_within_one_ulp(rt, program, weights, pi
     that are tiny through cancellation), and at most 0.2 % of the elements different at all (a different fp32 summation order may flip a rounding; nothing else may differ).
     The free-running comparison (test_bf16_network_deviation_is_reported) cannot be this tight: two bf16 pipelines
     that differ by one flipped rounding decorrelate to ~1 ulp rms within a few layers (see that test)."""
+    if pipelined:
+        _need_tile("bf16", 20)
     from yolo_v3_tf2_amd import _lib
     from oracle import oracle as O
     S, B = 96, 2
@@ -893,6 +931,7 @@ def test_608_end_to_end_detect(rt, program, weights, anchors):
     assert _boxes_close(gb, rb) and np.abs(gs - rs).max() <= 1e-4
     s2, n2 = O.nms_padded(gb, gs, 100, 0.5, 0.1)
     assert np.array_equal(s2, sel.cpu().numpy()) and np.array_equal(n2, nv.cpu().numpy())
+    _selection_explained((rb, rc, rs, rsel, rnv), (gb, cls.cpu().numpy(), gs, sel.cpu().numpy(), nv.cpu().numpy()))
     packed, nvd = net.detect(_cuda(x), anchors, 100, 0.5, 0.1)
     assert torch.equal(nvd, nv)
     pb, ps, pc, pi = rt.unpack_detections(packed)
@@ -937,12 +976,12 @@ def test_full_size_608_batch64_properties(rt, program, weights, anchors):
     for i in (7, B - 1):                                              # batch independence of the whole pipeline
         gi = net.forward(x[i:i + 1].contiguous())
         for a, b in zip(g1, gi):
-            assert float((a[i:i + 1] - b).abs().max()) <= 2e-5
+            assert torch.equal(a[i:i + 1], b)                         # bit for bit: no tile of the classic schedule splits a sum
         p1, n1 = net.detect(x[i:i + 1].contiguous(), anchors, 100, 0.5, 0.1)
         assert int(n1[0]) == int(nv[i])
         b_a, s_a, c_a, i_a = rt.unpack_detections(packed[i:i + 1])
         b_b, s_b, c_b, i_b = rt.unpack_detections(p1)
-        assert torch.equal(i_a, i_b) and torch.equal(c_a, c_b) and float((b_a - b_b).abs().max()) <= 1e-5
+        assert torch.equal(i_a, i_b) and torch.equal(c_a, c_b) and torch.equal(b_a, b_b)
     pb, ps, pc, pi = rt.unpack_detections(packed)
     psn, nvn = ps.cpu().numpy(), nv.cpu().numpy()
     for i in range(B):
@@ -1114,8 +1153,27 @@ def test_nms_kept_list_spills_past_lds_capacity(rt):
     assert int(is_copy[keep][sel2.cpu().numpy()[0, :int(nv2[0])]].sum()) == len(src) == 15
 
 
+def test_default_build_rejects_experimental_tiles(rt, program, weights):
+    """The default library does not carry the tiles that lost their A/Bs; asking for one is an error with a pointer to
+    the experimental build, never a silent substitute."""
+    from yolo_v3_tf2_amd import _lib
+    if _lib.tile_built(_lib.Y3_DTYPE_F32, 33):
+        pytest.skip("experimental library loaded")
+    net = rt.Net(program)
+    for t in (20, 25, 33, 40, 41, 45):
+        with pytest.raises(rt.Y3Error, match="not in this build"):
+            net.set_tile(10, t)
+    with pytest.raises(rt.Y3Error, match="not in this build"):
+        net.set_tile_bf16(10, 20)
+    with pytest.raises(rt.Y3Error):
+        net.set_tile_x2(10, 28)
+    net.set_tile(10, 31)
+    net.set_tile(10, -1)
+
+
 def test_probe_tiles_are_rejected(rt, program, weights, monkeypatch):
     """Timing-only ablation kernels (wrong results) are not reachable through the public setters."""
+    _need_tile("f32", 20)
     from yolo_v3_tf2_amd import _lib
     monkeypatch.delenv("Y3_ALLOW_PROBE_TILES", raising=False)
     net = rt.Net(program)
@@ -1261,10 +1319,9 @@ def test_end_to_end_detect(rt, program, weights, anchors):
     # (i) NMS bit-exact on identical inputs
     s2, n2 = O.nms_padded(gb, gs_, 100, 0.5, 0.1)
     assert np.array_equal(s2, gsel) and np.array_equal(n2, gnv)
-    # (ii) end-to-end selection
-    if not (np.array_equal(gsel, rsel) and np.array_equal(gnv, rnv)):
-        near = np.abs(rs - 0.1).min()
-        assert near < 1e-5, f"selection differs without a near-tie at the score threshold (closest {near})"
+    # (ii) end-to-end selection: equal, or every flip is a near-tie of the score threshold, the sort order or the IoU
+    # threshold (image, position, boxes and margin printed)
+    _selection_explained((rb, rc, rs, rsel, rnv), (gb, gc, gs_, gsel, gnv))
     assert np.array_equal(gc, rc) or np.abs(gs_ - rs).max() < 1e-4
 
 

@@ -248,3 +248,31 @@ def test_bf16_free_running_floor(program, weights):
     # every stored value is a bf16 number in both runs (the roundings are where they should be)
     for t in probe:
         assert np.array_equal(O.round_bf16(ka[t]), ka[t]) and np.array_equal(O.round_bf16(kb[t]), kb[t])
+
+
+def test_two_cpu_fp32_implementations_bound_the_box_bar(program, weights, anchors):
+    """Evidence under the box tolerance.  BASELINE.json says "boxes within 1e-4".  The same image
+    through TWO independent CPU fp32 implementations of the network (the C restatement and PyTorch-CPU/oneDNN; same
+    decode and NMS) already differs by MORE than 1e-4 in raw box coordinates: random-init heads emit unclipped boxes
+    tens of image widths wide (w = exp(tw) * anchor, reference core/yolo_decode_layer.py:23) and a 1e-5 summation-
+    order difference in tw scales with w.  Inside the unit range -- where a detection lives -- they agree to 1e-4
+    absolutely, and the deviation relative to max(1, |coord|) stays under 1e-4 as well.  That is the bar the GPU
+    tests use: strict absolute 1e-4 for |coord| <= 1, 1e-4 * |coord| beyond; it is a property of fp32 arithmetic on
+    these inputs, not slack granted to the kernel."""
+    from oracle import torch_ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img = O.decode_image_rgb01(os.path.join(root, "datasets/coco2012/images/girl.png"))
+    x = O.resize_bilinear(img, 416, 416)[None]
+    a = O.detect(program, weights, x, anchors)
+    b = torch_ref.detect(program, weights, x, anchors)
+    d = torch_ref.box_deviation(b[0], a[0], b[2], a[2])
+    print("cpu_vs_cpu", d)
+    assert d["largest_abs_box_coord"] > 10.0                       # the wide boxes are there
+    assert d["max_abs_dbox_raw"] > 1e-4                            # two CPU fp32 runs miss an absolute 1e-4 on them
+    assert d["max_abs_dbox_coords_within_unit_range"] <= 1e-4      # strict bar where |coord| <= 1
+    assert d["max_dbox_over_max1_abs_coord"] <= 1e-4               # scaled bar everywhere
+    assert d["max_abs_dscore"] <= 1e-4
+    # the two CPU runs pick the same detections; if they did not, the flip would have to be a near-tie
+    from oracle import flip_attribution as FA
+    flips = FA.attribute(a[0], a[2], a[3], a[4], b[0], b[2], b[3], b[4])
+    assert FA.explained(flips, d["max_abs_dscore"], d["max_abs_dbox_coords_within_unit_range"]), flips

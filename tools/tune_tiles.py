@@ -54,6 +54,11 @@ def main():
     if a.tiles == "all":   # timing-only probe tiles (wrong results) must be asked for by id; never with --write
         probes = _lib.PROBE_TILES_X2 if x2 else () if bf else _lib.PROBE_TILES
         tiles = [t for t in tiles if t not in probes]
+    dt_id = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3, "f32x2": _lib.Y3_DTYPE_F32X2}[a.dtype]
+    missing = [t for t in tiles if not _lib.tile_built(dt_id, t)]
+    if missing and a.tiles != "all":
+        sys.exit(f"tiles {missing} are not in this library: build csrc/build.py --experimental and set Y3_LIB_PATH")
+    tiles = [t for t in tiles if _lib.tile_built(dt_id, t)]     # experimental tiles only when the loaded library has them
     if x2:
         tiles = [t for t in tiles if t in _lib.TILES_X2_BUILT + _lib.PROBE_TILES_X2]
     elif x3:

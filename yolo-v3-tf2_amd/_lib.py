@@ -94,6 +94,7 @@ SYMBOLS = {
     "y3_version": (_i, []),
     "y3_last_error": (C.c_char_p, []),
     "y3_device_count": (_i, []),
+    "y3_tile_built": (_i, [_i, _i]),
     "y3_net_create": (_i, [C.POINTER(TensorDesc), _i, C.POINTER(C.c_int32), _i, C.POINTER(ConvDesc), _i,
                            C.POINTER(AuxDesc), _i, _i, C.POINTER(C.c_int32), _i, C.POINTER(_vp)]),
     "y3_net_destroy": (None, [_vp]),
@@ -146,6 +147,11 @@ def load():
             fn.restype, fn.argtypes = res, args
         _lib = lib
     return _lib
+
+
+def tile_built(dtype: int, tile: int) -> bool:
+    """False for the experimental tiles (probes, stream-K, residual prefetch, pipelined bf16) a default build omits."""
+    return bool(load().y3_tile_built(int(dtype), int(tile)))
 
 
 def check(status: int, what: str = ""):

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
 // staggered half, whose own wait is one interval later).  WAR: a half-tile is restaged two phases after its last read.
 // Limits: Cin % 64 == 0, CoutPad % 256 == 0, no concat source, bf16 output (residual optional), K / 64 >= 2.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef Y3_EXPERIMENTAL
 __global__ __launch_bounds__(512) void conv_bf16_pipe(const ConvArgs p)
 {
     constexpr int TM = 4, TN = 2, WR = 2, BK = 64;     // 2 x 4 waves, 128 x 64 per wave
@@ -565,6 +566,7 @@ static hipError_t launch_conv_bf16_pipe(const ConvArgs &a, bool out_f32, hipStre
     hipLaunchKernelGGL(conv_bf16_pipe, dim3(tilesM * tilesN), dim3(512), lds, s, a);
     return hipGetLastError();
 }
+#endif   // Y3_EXPERIMENTAL
 
 // tile table of the bf16 kernel: {BM, BN, waves, BK}
 static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
@@ -577,6 +579,16 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
 };
 
 TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < BF16_TILE_COUNT) ? tile : 0]; }
+
+bool conv_bf16_tile_built(int tile)
+{
+    if (tile < 0 || tile >= BF16_TILE_COUNT) return false;
+#ifdef Y3_EXPERIMENTAL
+    return true;
+#else
+    return tile != 20;   // the pipelined tile lost to tile 17: experimental builds only
+#endif
+}
 
 template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false>
 static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
@@ -607,9 +619,13 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
     const TileInfo t = kTilesBf16[tile];
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
     if (tile == 20) {   // the pipelined tile covers bf16-output convs with full 256-wide channel tiles; others run tile 17
+#ifdef Y3_EXPERIMENTAL
         if (!(out_f32 || a.src1 || a.Cin % 64 || a.CoutPad % 256 || a.Cout != a.CoutPad || a.K / 64 < 2))
             return launch_conv_bf16_pipe(a, out_f32, s);
         tile = 17;
+#else
+        return hipErrorInvalidValue;   // measured slower than tile 17 (profiles/r02_tile_sweep_bf16_pipelined_*): experimental builds only
+#endif
     }
     switch (tile) {
         case 0: return launch_tb<2, 2, 2, 2, 64>(a, out_f32, s);

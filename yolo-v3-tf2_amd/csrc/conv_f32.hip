@@ -538,6 +538,19 @@ static const TileInfo kTiles[TILE_COUNT] = {
 
 TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUNT) ? tile : 0]; }
 
+// Tiles 20..22, 25 (timing probes), 33..40 (stream-K) and 41..45 (residual prefetch) were measured
+// and lost (A/B records under profiles/r02_*): no tuning table or heuristic selects them, so the
+// default library does not carry their code.  csrc/build.py --experimental builds them (-DY3_EXPERIMENTAL).
+bool conv_tile_built(int tile)
+{
+    if (tile < 0 || tile >= TILE_COUNT) return false;
+#ifdef Y3_EXPERIMENTAL
+    return true;
+#else
+    return tile < 20 || tile == 23 || tile == 24 || (tile >= 26 && tile <= 32);
+#endif
+}
+
 template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0, int RESPF = 0>
 static hipError_t launch_k(const ConvArgs &a_in, hipStream_t s)
 {
@@ -609,10 +622,12 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 16: return launch_t<2, 1, 4, 4>(a, stages, s);           // 256x128, 16 waves
         case 17: case 19: return launch_t<1, 1, 4, 2>(a, stages, s);  // 128x64, 8 waves
         case 18: return launch_t<2, 1, 4, 2>(a, stages, s);           // 256x64, 8 waves
+#ifdef Y3_EXPERIMENTAL
         case 20: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 1>(a, s);  // probes (64x128)
         case 21: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 2>(a, s);
         case 22: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 3>(a, s);
         case 25: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 4>(a, s);
+#endif
         // direct-to-LDS operand loads, double buffered
         case 26: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 0, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 0, 1, 1>(a, s);  // 64x128
         case 27: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 0, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 0, 1, 1>(a, s);  // 64x64
@@ -621,6 +636,7 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 30: return a.src1 ? launch_k<2, 1, 4, 1, true, 2, 0, 1, 1>(a, s) : launch_k<2, 1, 4, 1, false, 2, 0, 1, 1>(a, s);  // 256x32
         case 31: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 1, 1>(a, s);  // 64x128, 1 stage
         case 32: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 1>(a, s);  // 64x64, 1 stage
+#ifdef Y3_EXPERIMENTAL
         // stream-K schedule (33..40 = tiles 10, 11, 9, 17, 26, 27, 31, 32)
         case 33: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 4, 0, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 4, 0, 1>(a, s);
         case 34: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 0, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 0, 1>(a, s);
@@ -636,6 +652,7 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 43: return (a.residual && !a.src1) ? launch_k<1, 1, 2, 2, false, 2, 0, 1, 1, 0, 1>(a, s) : launch_conv_f32(a, 27, s);
         case 44: return (a.residual && !a.src1) ? launch_k<1, 1, 2, 2, false, 1, 0, 1, 0, 0, 1>(a, s) : launch_conv_f32(a, 11, s);
         case 45: return (a.residual && !a.src1) ? launch_k<1, 2, 2, 2, false, 2, 0, 1, 1, 0, 1>(a, s) : launch_conv_f32(a, 26, s);
+#endif
         case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 3>(a, s);
         case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 4>(a, s);
         default: return hipErrorInvalidValue;

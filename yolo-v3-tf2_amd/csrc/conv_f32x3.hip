@@ -607,12 +607,15 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 12: return launch_tp<2, 2, 1, 2, 4, 32>(a, out_f32, s);      // 128x128 w8
         case 26: return launch_tp<2, 2, 1, 4, 4, 32>(a, out_f32, s);      // 256x128 w16
         case 27: return launch_tp<2, 2, 1, 2, 8, 32>(a, out_f32, s);      // 128x256 w16
+#ifdef Y3_EXPERIMENTAL
         case 28: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_A1>(a, out_f32, s);   // probe: 256x128 w16, A for tap 0 only
         case 29: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_A1>(a, out_f32, s);   // probe: 128x128 w8, A for tap 0 only
+#endif
         case 30: return launch_tp<2, 2, 1, 2, 4, 32, 3>(a, out_f32, s);      // 128x128 w8, three stages
         case 31: return launch_tp<2, 2, 1, 4, 4, 32, 3>(a, out_f32, s);      // 256x128 w16, three stages
         case 32: return launch_tp<2, 2, 2, 4, 2, 32, 3>(a, out_f32, s);      // 256x128 w8, three stages
         case 33: return launch_tp<2, 2, 1, 2, 8, 32, 3>(a, out_f32, s);      // 128x256 w16, three stages
+#ifdef Y3_EXPERIMENTAL
         case 34: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 256x128 w16, split K
         case 35: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 128x128 w8, split K
         case 36: return launch_tp<2, 2, 2, 4, 2, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 256x128 w8, split K
@@ -625,6 +628,7 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 43: return launch_tp<2, 2, 2, 4, 4, 32, 2, V_PROBE_1ACC>(a, out_f32, s);   // probe: 256x256 w16 (64x64 wave tiles), one accumulator set
         case 44: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_1ACC>(a, out_f32, s);   // probe: 256x128 w16, one accumulator set
         case 45: return launch_tp<2, 2, 2, 4, 2, 32, 2, V_PROBE_1ACC>(a, out_f32, s);   // probe: 256x128 w8, one accumulator set
+#endif
         default: return hipErrorInvalidValue;
     }
 }
@@ -634,7 +638,10 @@ bool conv_x3_tile_built(int tile) { return (tile >= 0 && tile <= 27) || tile == 
 bool conv_x2_tile_built(int tile)
 {
     switch (tile) {
-        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: case 40: case 41: case 42: case 43: case 44: case 45: return true;
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 30: case 31: case 32: case 33: return true;
+#ifdef Y3_EXPERIMENTAL
+        case 28: case 29: case 34: case 35: case 36: case 37: case 38: case 39: case 40: case 41: case 42: case 43: case 44: case 45: return true;   // timing-only probes
+#endif
         default: return false;
     }
 }

@@ -333,6 +333,17 @@ int y3_device_count(void)
     return n;
 }
 
+int y3_tile_built(int dtype, int tile)
+{
+    switch (dtype) {
+        case Y3_DTYPE_F32: return y3::conv_tile_built(tile) ? 1 : 0;
+        case Y3_DTYPE_BF16: return y3::conv_bf16_tile_built(tile) ? 1 : 0;
+        case Y3_DTYPE_F32X3: return (tile >= 0 && tile < y3::X3_TILE_COUNT && y3::conv_x3_tile_built(tile)) ? 1 : 0;
+        case Y3_DTYPE_F32X2: return (tile >= 0 && tile < y3::X3_TILE_COUNT && y3::conv_x2_tile_built(tile)) ? 1 : 0;
+        default: return 0;
+    }
+}
+
 y3_status y3_net_create(const y3_tensor_desc *tensors, int n_tensors, const int32_t *op_kinds, int n_ops,
                         const y3_conv_desc *convs, int n_convs, const y3_aux_desc *aux, int n_aux, int input_tensor,
                         const int32_t outputs[3], int nclasses, y3_net **out)
@@ -503,16 +514,49 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
     return Y3_OK;
 }
 
+// stream-K workspace of a planned fp32 net: 2 slabs per persistent workgroup (<= 2048 of them, <= 32 KB each) and one
+// ticket counter per output tile of the finest stream-K tile (64 x 64), per lane.  Counters are zeroed here
+// (synchronously) and returned to zero by the last contributor of every cut tile.
+static y3_status ensure_sk_workspace(y3_net *net)
+{
+    if (net->sk_ws) return Y3_OK;
+    HIP_TRY(hipSetDevice(net->device));
+    net->sk_ws_lane_bytes = (size_t)2 * 2048 * 32768;
+    long long cap = 1;
+    for (const ConvSlot &c : net->convs) {
+        const long long sp = net->image_size / c.d.out_div;
+        const long long tiles = (((long long)net->max_batch * sp * sp + 63) / 64) * ((c.cout_pad + 63) / 64);
+        if (!c.first_layer && tiles > cap) cap = tiles;
+    }
+    net->sk_cnt_cap = (int)((cap + 3) & ~3LL);
+    hipError_t e = hipMalloc(&net->sk_ws, net->sk_ws_lane_bytes * Y3_MAX_LANES);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&net->sk_cnt), (size_t)net->sk_cnt_cap * 4 * Y3_MAX_LANES);
+    if (e == hipSuccess) e = hipMemset(net->sk_cnt, 0, (size_t)net->sk_cnt_cap * 4 * Y3_MAX_LANES);
+    if (e != hipSuccess) {
+        if (net->sk_ws) (void)hipFree(net->sk_ws);
+        if (net->sk_cnt) (void)hipFree(net->sk_cnt);
+        net->sk_ws = nullptr;
+        net->sk_cnt = nullptr;
+        return fail(Y3_ERR_OOM, "stream-K workspace: %s", hipGetErrorString(e));
+    }
+    return Y3_OK;
+}
+
 y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
 {
     if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::TILE_COUNT)
         return fail(Y3_ERR_INVALID, "y3_net_set_tile: bad argument");
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
+        if (!y3::conv_tile_built(tile))
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile %d is not in this build (experimental tiles: csrc/build.py --experimental)", tile);
         if (is_probe_tile_f32(tile) && !probes_allowed())
             return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile %d is a timing-only probe (set Y3_ALLOW_PROBE_TILES=1 to use it)", tile);
         y3::TileInfo s = y3::conv_tile_info(tile);
         if (c.first_layer || c.cout_pad % s.bn) return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile does not divide Cout");
+        // a stream-K tile on an already planned fp32 net: its workspace is allocated on first use, not for everybody
+        if (s.sk && net->image_size && net->dtype == Y3_DTYPE_F32)
+            if (y3_status st = ensure_sk_workspace(net); st != Y3_OK) return st;
     }
     c.tile = tile;
     return Y3_OK;
@@ -524,6 +568,8 @@ y3_status y3_net_set_tile_bf16(y3_net *net, int slot, int tile)
         return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: bad argument");
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
+        if (!y3::conv_bf16_tile_built(tile))
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile %d is not in this build (csrc/build.py --experimental)", tile);
         y3::TileInfo s = y3::conv_bf16_tile_info(tile);
         if (c.first_layer || c.cout_pad % s.bn || c.d.cin % s.stages || (c.d.src1 >= 0 && c.d.c0 % s.stages))
             return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile does not fit this conv");
@@ -718,23 +764,16 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
     }
     if (y3_status st = ensure_lanes(net); st != Y3_OK) return st;
     if (dtype == Y3_DTYPE_F32) {
-        // stream-K workspace: 2 slabs per persistent workgroup (<= 2048 of them, <= 32 KB each) and one counter per
-        // output tile of the finest stream-K tile (64 x 64), per lane
-        net->sk_ws_lane_bytes = (size_t)2 * 2048 * 32768;
-        long long cap = 1;
-        for (const ConvSlot &c : net->convs) {
-            const long long sp = image_size / c.d.out_div;
-            const long long tiles = (((long long)max_batch * sp * sp + 63) / 64) * ((c.cout_pad + 63) / 64);
-            if (!c.first_layer && tiles > cap) cap = tiles;
-        }
-        net->sk_cnt_cap = (int)((cap + 3) & ~3LL);
-        hipError_t e = hipMalloc(&net->sk_ws, net->sk_ws_lane_bytes * Y3_MAX_LANES);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&net->sk_cnt), (size_t)net->sk_cnt_cap * 4 * Y3_MAX_LANES);
-        if (e == hipSuccess) e = hipMemset(net->sk_cnt, 0, (size_t)net->sk_cnt_cap * 4 * Y3_MAX_LANES);
-        if (e != hipSuccess) {
-            free_plan(net);
-            return fail(Y3_ERR_OOM, "y3_net_plan: stream-K workspace: %s", hipGetErrorString(e));
-        }
+        // stream-K tiles (experimental builds) sum cut tiles through a workspace: allocated only when a conv slot asks
+        // for such a tile -- here if one is already set, in y3_net_set_tile otherwise
+        bool any_sk = false;
+        for (const ConvSlot &c : net->convs)
+            if (c.tile >= 0 && y3::conv_tile_info(c.tile).sk) any_sk = true;
+        if (any_sk)
+            if (y3_status st = ensure_sk_workspace(net); st != Y3_OK) {
+                free_plan(net);
+                return st;
+            }
     }
     if (net->nclasses > 0) {   // scratch of y3_net_detect: no allocation inside the stream-ordered call
         size_t off[9], n_boxes, gelems[3];
@@ -964,6 +1003,7 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
     for (int i = 0; i < 3; ++i)
         if (!grids[i] || ((uintptr_t)grids[i] & 15)) return fail(Y3_ERR_INVALID, "y3_net_forward: grid %d null or not 16-byte aligned", i);
     if ((uintptr_t)images & 3) return fail(Y3_ERR_INVALID, "y3_net_forward: images not 4-byte aligned");
+    HIP_TRY(hipSetDevice(net->device));   // launches go to the net's device whatever the caller's current one is
     // Images are independent, so the batch can run as `lanes` sub-batches on forked streams: while one sub-batch's
     // conv kernel drains (its last workgroups leave CUs under-occupied), the other sub-batch's kernel fills them.
     net->cur_batch = batch;
@@ -1167,6 +1207,7 @@ y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const f
     if (batch > net->max_batch) return fail(Y3_ERR_INVALID, "y3_net_detect: batch %d > planned %d", batch, net->max_batch);
     if (max_boxes <= 0 || max_boxes > Y3_MAX_OUTPUT_BOXES)
         return fail(Y3_ERR_INVALID, "y3_net_detect: max_boxes must be in [1,%d]", Y3_MAX_OUTPUT_BOXES);
+    HIP_TRY(hipSetDevice(net->device));   // the decode / NMS / pack launches below go to the net's device, whatever the caller's current one
     int32_t gs[3];
     size_t gelems[3], n = 0, off[9];
     detect_layout(net, batch, off, &n, gs, gelems);

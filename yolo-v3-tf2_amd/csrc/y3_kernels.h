@@ -56,6 +56,7 @@ inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes)
 static constexpr int TILE_COUNT = 46;  // 20..22, 25: timing-only probes; 33..40: stream-K schedule; 41..45: residual prefetch
 struct TileInfo { int bm, bn, waves, stages; int sk = 0; };
 TileInfo conv_tile_info(int tile);
+bool conv_tile_built(int tile);        // false: experimental tile left out of this build
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
 // first layer: 3x3 stride-1 conv with Cin=3 (direct, VALU)
@@ -64,6 +65,7 @@ hipError_t launch_conv_first_f32(const ConvArgs &a, const float *w_hwio_dev, hip
 // bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
 static constexpr int BF16_TILE_COUNT = 21;
 TileInfo conv_bf16_tile_info(int tile);
+bool conv_bf16_tile_built(int tile);
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);
 hipError_t launch_conv_first_bf16(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void *x, float *y, size_t n, hipStream_t s);
