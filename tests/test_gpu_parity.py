@@ -1571,3 +1571,51 @@ def test_backbone_only_other_modes(rt, program, weights, mode):
             scale = max(1.0, float(np.abs(r).max()))
             tol = 3.0 * floor[k] if mode == "bf16" else 1e-4 * scale
             assert np.abs(g - r).max() <= tol, (mode, lanes, float(np.abs(g - r).max()), tol)
+
+
+def test_darknet_weights_file_to_device_detect(rt, program, weights, anchors, tmp_path):
+    """Row n1 on the GPU: a Darknet `.weights` file for the whole 75-conv program, laid out BY THIS TEST from the
+    reference's description of the format (reference convert.py:93-95 five int32 of header; :50-55 a batch-normalised
+    conv stores 4 x filters floats as beta, gamma, mean, var; :58 a bias conv its bias; :61-68 then
+    filters x in_dim x size x size weights in (Cout, Cin, kh, kw) order, conv by conv in creation order :96-137) --
+    not through this package's writer -- then `model.load_weights(path).expect_partial()` (reference inference.py:102)
+    -> DetectModel.predict on the device, against the oracle fed the very arrays the file was laid out from."""
+    import struct
+    from oracle import oracle as O
+    from yolo_v3_tf2_amd.core.parse_model import YoloModel
+    from yolo_v3_tf2_amd.inference import DetectModel
+    path = tmp_path / "hand_laid.weights"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<5i", 0, 2, 5, 32013312, 0))
+        for i, nd in enumerate(program.conv_nodes):
+            assert nd.conv_index == i
+            w = weights[f"conv{i}.w"]                                  # (kh, kw, Cin, Cout): the Keras layout
+            k, _, cin, cout = w.shape
+            if f"conv{i}.gamma" in weights:
+                for key in ("beta", "gamma", "mean", "var"):              # Darknet order
+                    f.write(np.asarray(weights[f"conv{i}.{key}"], "<f4").tobytes())
+            else:
+                f.write(np.asarray(weights[f"conv{i}.bias"], "<f4").tobytes())
+            dk = np.empty((cout, cin, k, k), "<f4")                        # element by element: no transpose helper
+            for u in range(k):
+                for v in range(k):
+                    dk[:, :, u, v] = w[u, v].T
+            f.write(dk.tobytes())
+    assert os.path.getsize(path) == 20 + 4 * program.n_params()
+    S, B = 160, 2
+    x = np.random.default_rng(77).random((B, S, S, 3), dtype=np.float32)
+    model = YoloModel(program)
+    status = model.load_weights(str(path))
+    status.expect_partial()
+    det = DetectModel(model, anchors, 80, 100, 0.5, 0.1)
+    gb, gc, gs_, gsel, gnv = det.predict(x)
+    rb, rc, rs, rsel, rnv = O.detect(program, weights, x, anchors)
+    assert _boxes_close(gb, rb) and np.abs(gs_ - rs).max() <= 1e-4
+    s2, n2 = O.nms_padded(gb, gs_, 100, 0.5, 0.1)
+    assert np.array_equal(s2, gsel) and np.array_equal(n2, gnv)
+    _selection_explained((rb, rc, rs, rsel, rnv), (gb, gc, gs_, gsel, gnv))
+    # and the file path gives bit for bit what the in-memory path gives (the loader changes no value)
+    m2 = YoloModel(program)
+    m2.set_weights_dict(weights)
+    hb, hc, hs, hsel, hnv = DetectModel(m2, anchors, 80, 100, 0.5, 0.1).predict(x)
+    assert np.array_equal(hb, gb) and np.array_equal(hs, gs_) and np.array_equal(hsel, gsel)
