@@ -84,10 +84,10 @@ class SclkSampler:
         self.src = []
         for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             hw = sorted(glob.glob(os.path.join(card, "hwmon/hwmon*/freq1_input")))
-            if hw:
-                self.src.append(("hz", hw[0]))
-            elif os.path.exists(os.path.join(card, "pp_dpm_sclk")):
+            if os.path.exists(os.path.join(card, "pp_dpm_sclk")):     # what rocm-smi --showclocks reports
                 self.src.append(("dpm", os.path.join(card, "pp_dpm_sclk")))
+            elif hw:
+                self.src.append(("hz", hw[0]))
         self.samples = [[] for _ in self.src]
         self._stop = None
         self._th = None
@@ -476,6 +476,9 @@ def main():
             net.plan(B, S, dt_ids[args.dtype])       # the alt measurements re-planned the net: back to the headline mode
             ms = net.profile_convs(images)
             for o, t in zip(net.conv_ops, ms):
+                if t <= 0:      # conv0 of the fused stem: its work is inside conv1's launch
+                    print(f"conv{o.conv_index:<3d} {o.size}x{o.size}/{o.stride} {o.cin:>4d}->{o.cout:<4d}  (fused into the next launch)", file=sys.stderr)
+                    continue
                 ho = S // o.out_div
                 fl = 2.0 * o.size * o.size * o.cin * o.cout * ho * ho * B
                 print(f"conv{o.conv_index:<3d} {o.size}x{o.size}/{o.stride} {o.cin:>4d}->{o.cout:<4d} @{ho:<3d} "

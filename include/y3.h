@@ -132,6 +132,11 @@ y3_status y3_net_set_sk_grid(y3_net *net, int workgroups);
  * Results are bit-identical in both modes (same per-tile arithmetic). */
 y3_status y3_net_set_xcd_mode(y3_net *net, int mode);
 y3_status y3_net_keep_activations(y3_net *net, int keep);
+/* 1 (default): when the program starts with conv0 (3x3/1, 3 -> 32) feeding only conv1 (3x3/2, 32 -> 64) -- the Darknet-53
+ * stem, reference config/models/yolov3/backbone.yaml layers 1-2 -- and the plan is fp32 without keep_activations, the two
+ * run as ONE kernel that keeps conv0's output (the largest tensor of the network, 1.4 GB at 64 x 416^2) in LDS.
+ * 0: one launch per conv.  Results agree to fp32 rounding (conv0's summation order differs between the two kernels). */
+y3_status y3_net_set_stem_fusion(y3_net *net, int on);
 /* Before y3_net_plan: run the first n_convs convs chunk_images images at a time, then the rest of the network on the
  * whole batch.  The first layers' activations are the largest tensors of the network (1.4 GB for 64 images at 416x416);
  * in chunks they are still in the Infinity Cache when the next conv reads them.  Results are unchanged (images are

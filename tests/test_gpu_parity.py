@@ -837,6 +837,9 @@ def test_early_chunk_bit_identical(rt, program, weights, mode):
     x = _cuda(np.random.default_rng(16).random((7, 96, 96, 3), dtype=np.float32))
     net = rt.Net(program)
     net.load_weights(weights)
+    # same kernels in both schedules: the chunked leading segment runs conv0 and conv1 as two launches (the fused stem
+    # sums conv0's 27 products in another order), so the reference run does too
+    net.set_stem_fusion(False)
     net.plan(7, 96, dt)
     net.set_lanes(1)
     a = [g.clone() for g in net.forward(x)]
@@ -1619,3 +1622,52 @@ def test_darknet_weights_file_to_device_detect(rt, program, weights, anchors, tm
     m2.set_weights_dict(weights)
     hb, hc, hs, hsel, hnv = DetectModel(m2, anchors, 80, 100, 0.5, 0.1).predict(x)
     assert np.array_equal(hb, gb) and np.array_equal(hs, gs_) and np.array_equal(hsel, gsel)
+
+
+@pytest.mark.parametrize("S,B", [(32, 1), (64, 3), (96, 2), (416, 1)])
+def test_fused_stem_matches_oracle_and_the_two_launch_form(rt, S, B):
+    """conv0 (3x3/1, 3 -> 32) + conv1 (3x3/2, 32 -> 64) as ONE kernel (csrc/conv_stem.hip; reference
+    core/parse_model.py:27-52, the stride-2 conv padded top/left only :34-35): conv1's output against the oracle's
+    layer-by-layer result within the layer bar, and against the two-launch form (same bar: conv0's summation order
+    differs between the two kernels).  Sizes cover one tile per image row (32), borders on every side, several images
+    and the real 416 geometry; the fused form must really be the one that ran (conv0 reports no launch of its own)."""
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from oracle import oracle as O
+    p = mini_program(3, [dict(filters=32, size=3), dict(filters=64, size=3, stride=2)],
+                     [dict(filters=32, size=1), dict(filters=32, size=1), dict(filters=32, size=1)])
+    w = synthetic_weights(p, seed=11)
+    x = np.random.default_rng(11).random((B, S, S, 3), dtype=np.float32)
+    t1 = p.conv_ops()[1].dst
+    ref, kept = O.forward(p, w, x, keep={t1})
+    xd = _cuda(x)
+    outs = {}
+    for fused in (True, False):
+        net = rt.Net(p)
+        net.load_weights(w)
+        net.plan(B, S)
+        net.set_stem_fusion(fused)
+        got = [g.clone() for g in net.forward(xd)]
+        ms = net.profile_convs(xd)
+        assert (ms[0] == 0.0) == fused, "fused stem did not engage" if fused else "fusion could not be switched off"
+        outs[fused] = got
+        for r, g in zip(ref, got):
+            g = g.cpu().numpy().reshape(r.shape)
+            assert np.abs(g - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max())), (fused, float(np.abs(g - r).max()))
+    for a, b in zip(outs[True], outs[False]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    # determinism of the persistent kernel
+    net = rt.Net(p)
+    net.load_weights(w)
+    net.plan(B, S)
+    again = net.forward(xd)
+    assert all(torch.equal(a, b) for a, b in zip(outs[True], again))
+    # keep_activations needs conv0's tensor in HBM: the fusion steps aside and the tensor is readable
+    net = rt.Net(p)
+    net.load_weights(w)
+    net.keep_activations(True)
+    net.plan(B, S)
+    net.forward(xd)
+    c1 = net.read_tensor(t1, B).cpu().numpy()
+    assert np.abs(c1 - kept[t1]).max() <= 2e-5 * max(1.0, float(np.abs(kept[t1]).max()))
+    assert net.profile_convs(xd)[0] > 0.0

@@ -461,8 +461,11 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     // turns into "load 0 / drop the store"; the 16 residual loads of a sub-tile are issued together.
     // interior tiles (the common case): one per-lane voffset per sub-tile, the row displacement of accumulator
     // element e rides in the scalar soffset -> no per-element address or bounds arithmetic on the VALU
-    auto emit = [&](auto leaky_tag, auto res_tag) {
+    auto emit = [&](auto leaky_tag, auto res_tag, auto interior_tag) {
         constexpr bool LEAKY = decltype(leaky_tag)::value, RES = decltype(res_tag)::value;
+        // shadows the run-time flag: straight-line code per case (the run-time form compiled to a branch around every
+        // load and store; A/B r03: conv stack -0.07 %, i.e. neutral -- kept for the shorter instruction stream)
+        constexpr bool interior = decltype(interior_tag)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wc * TN + j) * 32 + fr;
@@ -508,12 +511,15 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
+    auto emit2 = [&](auto leaky_tag, auto res_tag) {
+        if (interior) emit(leaky_tag, res_tag, T_{}); else emit(leaky_tag, res_tag, F_{});
+    };
     if (RESPF) {                       // built for residual convs only (launch_conv_f32 guarantees p.residual)
-        if (p.leaky) emit(T_{}, T_{}); else emit(F_{}, T_{});
+        if (p.leaky) emit2(T_{}, T_{}); else emit2(F_{}, T_{});
     } else if (p.residual) {
-        if (p.leaky) emit(T_{}, T_{}); else emit(F_{}, T_{});
+        if (p.leaky) emit2(T_{}, T_{}); else emit2(F_{}, T_{});
     } else {
-        if (p.leaky) emit(T_{}, F_{}); else emit(F_{}, F_{});
+        if (p.leaky) emit2(T_{}, F_{}); else emit2(F_{}, F_{});
     }
   } while (SK && (it += seg_k1 - seg_k0, first_segment = false, it < it_end));
 }

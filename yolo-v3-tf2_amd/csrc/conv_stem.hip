@@ -1,0 +1,294 @@
+// Fused network stem on the gfx950 matrix cores: conv0 (3x3 / 1, 3 -> 32, BN, LeakyReLU) feeding conv1 (3x3 / 2, 32 -> 64,
+// BN, LeakyReLU) in ONE kernel -- the 416^2 x 32 tensor between them (1.42 GB for 64 images, the largest tensor of the
+// network) is never written to or read from HBM.
+//
+// Replaces the first two Conv2D -> BatchNormalization -> LeakyReLU groups of the backbone
+// (reference: core/parse_model.py:27-52 applied to config/models/yolov3/backbone.yaml layers 1 and 2; the stride-2 conv
+// pads top/left only, reference: core/parse_model.py:34-35).
+//
+// One persistent workgroup (8 waves) per CU walks output tiles of 8 x 16 conv1 pixels.  Per tile:
+//   phase 1  conv0 for the 17 x 33 conv0 pixels the tile's 3x3/2 windows cover, on v_mfma_f32_32x32x2_f32 (K = 27 padded
+//            to 28) from a 19 x 35 x 3 image patch in LDS; result (+shift, leaky) goes to an LDS patch [pixel][32 ch].
+//            conv0 positions outside the image (row / column -1: conv1's zero padding) are written as 0.
+//   phase 2  conv1 as an implicit GEMM 128 pixels x 64 channels x K = 288 read ENTIRELY from LDS: A fragments from the
+//            patch, B fragments from the conv1 weights, which stay LDS-resident for the whole kernel.  No global load, no
+//            barrier and (all addresses = per-lane base + immediate) no vector ALU instruction inside the K loop.
+// Recompute: 561 conv0 pixels per 512 consumed = 1.10 x the conv0 FLOPs (0.45 % of the network's).
+//
+// LDS (153,516 B of the CU's 160 KB; one workgroup per CU):
+//   patch  17*33 pixels x 128 B; pixel (y, x) at index y*33 + (x >> 1) + (x & 1)*17 (even columns first: the stride-2
+//          windows of 16 consecutive output pixels then touch consecutive indices), 16-B chunk c stored at chunk
+//          c ^ (((x >> 1) + (y >> 1)) & 7): every ds_read_b128 of phase 2 is bank-conflict free (checked exhaustively over
+//          taps, sub-tiles and k chunks with the lane groups of MI355X_MICROARCH.md, LDS section).
+//   w1     64 rows x 288 floats, chunk kc of row n stored at (kc & ~7) | ((kc & 7) ^ ((n >> 1) & 7)).
+//   img    19 x 35 x 3 floats.
+// Summation order per output element: conv0 k = 0, 14, 1, 15, ... (two interleaved halves of the 27 taps x channels);
+// conv1 identical to conv_f32_mfma (tap-major, 8q+t / 8q+4+t).  The order is the same for every pixel of every image.
+#include <type_traits>
+
+#include "y3_kernels.h"
+
+namespace y3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace stem {
+constexpr int TH = 8, TW = 16;            // conv1 output pixels per tile
+constexpr int PH = 2 * TH + 1, PW = 2 * TW + 1;   // conv0 patch: 17 x 33
+constexpr int IH = PH + 2, IW = PW + 2;   // image patch: 19 x 35
+constexpr int C0 = 32, C1 = 64, K1 = 9 * C0;
+constexpr int PATCH_F = PH * PW * C0;     // 17952 floats
+constexpr int W1_F = C1 * K1;             // 18432 floats
+constexpr int IMG_F = IH * IW * 3;        // 1995 floats
+constexpr int NT = 512;
+constexpr int LDS_BYTES = (PATCH_F + W1_F + IMG_F) * 4;
+constexpr int IMG_PER_THREAD = (IMG_F + NT - 1) / NT;   // 4
+
+// float offset inside the image patch of conv0's k-th operand, k = (u*3 + v)*3 + c
+__host__ __device__ constexpr int img_off(int k) { return k < 27 ? ((k / 9) * IW + (k / 3) % 3) * 3 + k % 3 : 0; }
+}  // namespace stem
+
+__global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
+{
+    using namespace stem;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;
+    float *w1s = smem + PATCH_F;
+    float *imgs = smem + PATCH_F + W1_F;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+
+    // ---- once per workgroup: conv1 weights into LDS (swizzled), conv0 weight fragments and shifts into registers ----
+    for (int g = tid; g < C1 * (K1 / 4); g += NT) {
+        const int n = g / (K1 / 4), kc = g - n * (K1 / 4);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(p.w1 + n * K1 + kc * 4);
+        const int kp = (kc & ~7) | ((kc & 7) ^ ((n >> 1) & 7));
+        *reinterpret_cast<f32x4 *>(w1s + n * K1 + kp * 4) = v;
+    }
+    float b0[14];            // conv0 B fragments: lane (n = fr, half fh) holds w0[k = s + 14*fh][n]
+    int d0[14];              // byte offset of operand k = s + 14*fh inside the image patch
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        b0[s] = p.w0[(s + 14 * fh) * C0 + fr];
+        d0[s] = (fh ? img_off(s + 14) : img_off(s)) * 4;
+    }
+    const float sh0 = p.shift0[fr];
+    // phase-2 role of this wave: rows [2*wm, 2*wm + 2) of the tile x channels [32*wn, +32)
+    const int wm = wave >> 1, wn = wave & 1;
+    const float sh1 = p.shift1[wn * 32 + fr];
+
+    // ---- per-lane address pieces (all loop invariant) ----
+    // phase 1, row sub-tiles: this wave computes patch rows y = 2*wave and 2*wave + 1 (wave 0 also row 16), 32 pixels
+    // x = 0..31 each (lane row = fr); wave 1 also the column x = 32 (17 pixels, lane row = y).
+    // A operand: image patch float ((y + u)*IW + x + v)*3 + c  ->  per lane (fr*3)*4 + d0[s], rows by immediates.
+    int a1[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) a1[s] = (2 * wave * IW * 3 + fr * 3) * 4 + d0[s];
+    // phase 1 write: accumulator element e of lane (fr = channel n, fh): pixel x = xe + 4*fh, xe = (e & 3) + 8*(e >> 2).
+    //   index = y*33 + (x >> 1) + (x & 1)*17 = y*33 + 2*fh + [(xe >> 1) + (xe & 1)*17]
+    //   chunk = (n >> 2) ^ (((x >> 1) + (y >> 1)) & 7) = (n >> 2) ^ ((ce + 2*fh + wave) & 7), ce = xe >> 1, y >> 1 == wave
+    //   (row 16 of wave 0: y >> 1 = 8 == 0 mod 8).  xr[k] = float offset of channel n inside a pixel whose swizzle key is
+    //   (k + 2*fh + wave) & 7 -- element e uses xr[ce & 7], a compile-time index.
+    int xr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xr[k] = ((((fr >> 2) ^ ((k + 2 * fh + wave) & 7)) << 2) | (fr & 3)) * 4;
+    // phase 2 A operand: lane row fr -> tile pixel (r = 2*wm + (fr >> 4), c = fr & 15); tap (u, v):
+    //   y = 2r + u, x = 2c + v; index = 66 r + c + [33 u + (v >> 1) + 17 (v & 1)];  key = (c + r + (u >> 1) + (v >> 1)) & 7
+    const int pr = 2 * wm + (fr >> 4), pc = fr & 15;
+    int a2[3][4];            // [tap key offset t = (u >> 1) + (v >> 1)][k chunk q]: byte address without the tap's immediate
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            a2[t][q] = ((66 * pr + pc) * C0 + (((2 * q + fh) ^ ((pc + pr + t) & 7)) << 2)) * 4;
+    int bw[4];               // phase 2 B operand: row n = 32*wn + fr of w1, k chunk q of a tap (tap * 128 B as immediate)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        bw[q] = (PATCH_F + (wn * 32 + fr) * K1 + (((2 * q + fh) ^ (((wn * 32 + fr) >> 1) & 7)) << 2)) * 4;
+
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.img), 0, p.img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
+    const int S = p.S, So = p.S >> 1;
+    const int tiles_per_img = p.tiles_y * p.tiles_x;
+    const char *lds = reinterpret_cast<const char *>(smem);
+
+    // image patch of a tile: element i of the 19 x 35 x 3 patch <- image (iy0 + i / 105, ix0 + (i % 105) / 3, channel);
+    // positions outside the image read as 0 (conv0's 'same' padding) through the buffer range check
+    auto img_voff = [&](int tile, unsigned (&vo)[IMG_PER_THREAD]) {
+        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
+        const int ty = t2 / p.tiles_x, tx = t2 - ty * p.tiles_x;
+        const int iy0 = 2 * ty * TH - 2, ix0 = 2 * tx * TW - 2;
+#pragma unroll
+        for (int i = 0; i < IMG_PER_THREAD; ++i) {
+            const int e = tid + i * NT;
+            const int iy = e / (IW * 3), rem = e - iy * (IW * 3);
+            const int ix = rem / 3, c = rem - ix * 3;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            const bool ok = e < IMG_F && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S;
+            vo[i] = ok ? (unsigned)(((b * S + gy) * S + gx) * 3 + c) * 4u : p.img_bytes;
+        }
+    };
+    float rimg[IMG_PER_THREAD];
+    auto img_fetch = [&](const unsigned (&vo)[IMG_PER_THREAD]) {
+#pragma unroll
+        for (int i = 0; i < IMG_PER_THREAD; ++i)
+            rimg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, (int)vo[i], 0, 0));
+    };
+    auto img_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < IMG_PER_THREAD; ++i)
+            if (tid + i * NT < IMG_F) imgs[tid + i * NT] = rimg[i];
+    };
+
+    int tile = blockIdx.x;
+    if (tile < p.n_tiles) {
+        unsigned vo[IMG_PER_THREAD];
+        img_voff(tile, vo);
+        img_fetch(vo);
+        img_stage();
+    }
+    __syncthreads();
+
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
+        const int ty = t2 / p.tiles_x, tx = t2 - ty * p.tiles_x;
+
+        // ================= phase 1: conv0 into the LDS patch =================
+        // one row sub-tile: patch row y (wave-uniform), pixels x = 0..31
+        auto conv0_row = [&](auto ytag) {
+            constexpr int YD = decltype(ytag)::value;       // row relative to the wave's first row (0, 1, or 16 for wave 0)
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            float a[14];
+#pragma unroll
+            for (int s = 0; s < 14; ++s)
+                a[s] = *reinterpret_cast<const float *>(lds + (PATCH_F + W1_F) * 4 + a1[s] + YD * IW * 3 * 4);
+#pragma unroll
+            for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc, 0, 0, 0);
+            const int y = 2 * wave + YD;
+            // conv0 positions outside the image = conv1's zero padding: patch row 0 of the first tile row, column 0 of
+            // the first tile column
+            const bool zrow = (ty == 0) && (y == 0);
+            const int base = ((y * PW + 2 * fh) * C0) * 4;
+            int wa[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wa[k] = base + xr[k];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int xe = (e & 3) + 8 * (e >> 2);
+                float v = acc[e] + sh0;
+                if (p.leaky0) v = fmaxf(v, 0.1f * v);
+                const bool zero = zrow || (tx == 0 && xe == 0 && fh == 0);
+                v = zero ? 0.0f : v;
+                const int imm = (((xe >> 1) + (xe & 1) * 17) * C0) * 4;
+                *reinterpret_cast<float *>(const_cast<char *>(lds) + wa[(xe >> 1) & 7] + imm) = v;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I16 = std::integral_constant<int, 16>;
+        conv0_row(I0{});
+        conv0_row(I1{});
+        if (wave == 0) conv0_row(I16{});
+        if (wave == 1) {
+            // column sub-tile: x = 32, lane row = y (17 of 32 rows used)
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            const int yl = fr < PH ? fr : PH - 1;
+            const int abase = (PATCH_F + W1_F) * 4 + ((yl * IW + 32) * 3) * 4;
+            float a[14];
+#pragma unroll
+            for (int s = 0; s < 14; ++s) a[s] = *reinterpret_cast<const float *>(lds + abase + d0[s]);
+#pragma unroll
+            for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int y = (e & 3) + 8 * (e >> 2) + 4 * fh;        // accumulator row = patch row
+                float v = acc[e] + sh0;
+                if (p.leaky0) v = fmaxf(v, 0.1f * v);
+                v = (ty == 0 && y == 0) ? 0.0f : v;
+                // x = 32: index y*33 + 16, key (16 + (y >> 1)) & 7
+                const int off = ((y * PW + 16) * C0 + ((((fr >> 2) ^ ((y >> 1) & 7)) << 2) | (fr & 3))) * 4;
+                if (y < PH) *reinterpret_cast<float *>(const_cast<char *>(lds) + off) = v;
+            }
+        }
+        __syncthreads();   // patch complete; the image patch is free
+
+        // prefetch the next tile's image patch: in flight during phase 2, staged before the closing barrier
+        const int next = tile + gridDim.x;
+        if (next < p.n_tiles) {
+            unsigned vo[IMG_PER_THREAD];
+            img_voff(next, vo);
+            img_fetch(vo);
+        }
+
+        // ================= phase 2: conv1 from LDS =================
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int t = (u >> 1) + (v >> 1);
+                const int aimm = ((33 * u + (v >> 1) + 17 * (v & 1)) * C0) * 4;
+                const int bimm = ((u * 3 + v) * C0) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 fa = *reinterpret_cast<const f32x4 *>(lds + a2[t][q] + aimm);
+                    const f32x4 fb = *reinterpret_cast<const f32x4 *>(lds + bw[q] + bimm);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k], fb[k], acc, 0, 0, 0);
+                }
+            }
+
+        // ---- epilogue: accumulator element e = tile pixel row (e & 3) + 8*(e >> 2) + 4*fh of this wave's 32, channel fr ----
+        {
+            const int oy0 = ty * TH + 2 * wm, ox0 = tx * TW;
+            const int n = wn * 32 + fr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2);               // + 4*fh: pixel (row + 4 fh) >> 4, & 15
+                const int rr = (row >> 4), cc = (row & 15) + 4 * fh;  // row & 15 + 4 fh < 16: rows 0-3, 8-11 (+4) only
+                float v = acc[e] + sh1;
+                if (p.leaky1) v = fmaxf(v, 0.1f * v);
+                const unsigned off = (unsigned)((((b * So + oy0 + rr) * So) + ox0 + cc) * C1 + n) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, (int)off, 0, 0);
+            }
+        }
+        if (next < p.n_tiles) img_stage();
+        __syncthreads();   // patch free for the next tile; its image patch is in place
+    }
+}
+
+hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s)
+{
+    using namespace stem;
+    if (a.S % 32 || a.B <= 0 || !a.img || !a.w0 || !a.w1 || !a.dst) return hipErrorInvalidValue;
+    StemArgs p = a;
+    p.tiles_y = (a.S / 2) / TH;
+    p.tiles_x = (a.S / 2) / TW;
+    p.n_tiles = a.B * p.tiles_y * p.tiles_x;
+    static LdsAttrOnce attr;
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv_stem_f32), LDS_BYTES); e != hipSuccess) return e;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+        cus[dev] = n > 0 ? n : 256;
+    }
+    const int grid = p.n_tiles < cus[dev] ? p.n_tiles : cus[dev];   // one persistent workgroup per CU
+    hipLaunchKernelGGL(conv_stem_f32, dim3(grid), dim3(NT), LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace y3

@@ -71,6 +71,7 @@ struct ConvSlot {
     bool x2_ok = true;         // false: a BN-scaled weight is outside the fp16 range, the two-plane mode cannot be planned
     void *wx2_dev = nullptr;   // packed [CoutPad64][2 planes][K] fp16 (h, l' = (w - h) * 2^11 of the BN-scaled weights)
     float *w_dev = nullptr;    // packed [CoutPad][K] (or HWIO for the first layer)
+    float *w0stem_dev = nullptr;   // first layer only: [28][Cout] = HWIO rows x BN scale, row 27 zero (fused stem kernel)
     void *wbf_dev = nullptr;   // same, bf16 (not for the first layer)
     float *scale_dev = nullptr;
     float *shift_dev = nullptr;
@@ -115,6 +116,8 @@ struct y3_net {
     int *sk_cnt = nullptr;
     size_t sk_ws_lane_bytes = 0;
     int sk_cnt_cap = 0;
+    int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 as one kernel when the graph allows it
+    bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
     int xcd_mode = 1;              // y3_net_set_xcd_mode: 0 contiguous tile runs per XCD, 1 XCD-blocked order chosen per conv
     int sk_grid = 0;               // y3_net_set_sk_grid: > 0 overrides the number of persistent workgroups (tests)
     int cur_batch = 1;             // batch of the forward being enqueued
@@ -320,6 +323,31 @@ int choose_tile(const ConvSlot &c, long long M)
 
 }  // namespace
 
+// The first two ops are conv0 (3x3/1, 3 -> 32) and conv1 (3x3/2, 32 -> 64, no shortcut, single source) reading it, nobody
+// else reads conv0's output, and the plan is fp32 with every intermediate reusable: the pair runs as csrc/conv_stem.hip.
+static bool stem_applicable(const y3_net *net)
+{
+    if (net->dtype != Y3_DTYPE_F32 || net->keep_all || net->image_size % 32 || net->early_ops > 0) return false;
+    if (net->ops.size() < 2 || net->ops[0].kind != 0 || net->ops[1].kind != 0) return false;
+    const ConvSlot &c0 = net->convs[net->ops[0].index], &c1 = net->convs[net->ops[1].index];
+    const y3_conv_desc &a = c0.d, &b = c1.d;
+    if (!c0.first_layer || a.size != 3 || a.stride != 1 || a.cout != 32 || a.residual >= 0 || a.src1 >= 0) return false;
+    if (b.size != 3 || b.stride != 2 || b.cin != 32 || b.cout != 64 || b.residual >= 0 || b.src1 >= 0 || b.src0 != a.dst) return false;
+    if (a.src0 != net->input_tensor) return false;
+    for (int k = 0; k < 3; ++k)
+        if (net->outputs[k] == a.dst || net->outputs[k] == b.dst) return false;
+    for (size_t i = 2; i < net->ops.size(); ++i) {
+        if (net->ops[i].kind == 0) {
+            const y3_conv_desc &d = net->convs[net->ops[i].index].d;
+            if (d.src0 == a.dst || d.src1 == a.dst || d.residual == a.dst) return false;
+        } else {
+            const y3_aux_desc &x = net->aux[net->ops[i].index];
+            if (x.src0 == a.dst || x.src1 == a.dst) return false;
+        }
+    }
+    return true;
+}
+
 extern "C" {
 
 int y3_version(void) { return 100; }
@@ -421,6 +449,7 @@ void y3_net_destroy(y3_net *net)
     }
     for (ConvSlot &c : net->convs) {
         if (c.w_dev) (void)hipFree(c.w_dev);
+        if (c.w0stem_dev) (void)hipFree(c.w0stem_dev);
         if (c.wbf_dev) (void)hipFree(c.wbf_dev);
         if (c.wx3_dev) (void)hipFree(c.wx3_dev);
         if (c.wx2_dev) (void)hipFree(c.wx2_dev);
@@ -472,6 +501,14 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
     if (!c.scale_dev) HIP_TRY(hipMalloc(&c.scale_dev, CP64 * sizeof(float)));
     if (!c.shift_dev) HIP_TRY(hipMalloc(&c.shift_dev, CP64 * sizeof(float)));
     HIP_TRY(hipMemcpy(c.w_dev, (c.first_layer ? pk : pk_scaled).data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (c.first_layer) {
+        // fused stem kernel: conv0 on the matrix cores wants K = 27 padded to 28 and the BN scale folded in
+        std::vector<float> w28((size_t)28 * d.cout, 0.0f);
+        for (int k = 0; k < K; ++k)
+            for (int n = 0; n < d.cout; ++n) w28[(size_t)k * d.cout + n] = w[(size_t)k * d.cout + n] * scale[n];
+        if (!c.w0stem_dev) HIP_TRY(hipMalloc(&c.w0stem_dev, w28.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(c.w0stem_dev, w28.data(), w28.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (!c.first_layer) {
         std::vector<unsigned short> pb(pk.size());
         for (size_t i = 0; i < pk.size(); ++i) pb[i] = f32_to_bf16_rne(pk[i]);
@@ -613,6 +650,15 @@ y3_status y3_net_set_lanes(y3_net *net, int lanes)
 {
     if (!net || lanes < 1 || lanes > Y3_MAX_LANES) return fail(Y3_ERR_INVALID, "y3_net_set_lanes: lanes must be in [1,%d]", Y3_MAX_LANES);
     net->lanes = lanes;
+    return Y3_OK;
+}
+
+y3_status y3_net_set_stem_fusion(y3_net *net, int on)
+{
+    if (!net || on < 0 || on > 1) return fail(Y3_ERR_INVALID, "y3_net_set_stem_fusion: argument must be 0 or 1");
+    net->stem_mode = on;
+    // takes effect at once on a planned net when the graph qualifies (decided again by the next y3_net_plan)
+    if (net->image_size) net->stem_fused = on && stem_applicable(net);
     return Y3_OK;
 }
 
@@ -775,6 +821,7 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
                 return st;
             }
     }
+    net->stem_fused = net->stem_mode && stem_applicable(net);
     if (net->nclasses > 0) {   // scratch of y3_net_detect: no allocation inside the stream-ordered call
         size_t off[9], n_boxes, gelems[3];
         int32_t gs[3];
@@ -905,9 +952,29 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.sk_grid_override = net->sk_grid;
             a.xcd_gn = 0;
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
+            if (net->stem_fused && oi == 0) {       // conv0 runs inside conv1's launch (fused stem)
+                if (ms_out && o.index < n_ms) ms_out[o.index] = 0.0f;
+                continue;
+            }
             if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
             hipError_t e;
-            if ((bf || x3 || x2) && c.first_layer) {
+            if (net->stem_fused && oi == 1) {
+                const ConvSlot &c0 = net->convs[net->ops[0].index];
+                y3::StemArgs sa{};
+                sa.img = static_cast<const float *>(ptr(c0.d.src0));
+                sa.w0 = c0.w0stem_dev;
+                sa.shift0 = c0.shift_dev;
+                sa.w1 = c.w_dev;
+                sa.shift1 = c.shift_dev;
+                sa.dst = a.dst;
+                sa.B = nb;
+                sa.S = net->image_size;
+                sa.leaky0 = c0.d.leaky;
+                sa.leaky1 = d.leaky;
+                sa.img_bytes = (unsigned)bytes(c0.d.src0);
+                sa.dst_bytes = a.dst_bytes;
+                e = y3::launch_conv_stem_f32(sa, s);
+            } else if ((bf || x3 || x2) && c.first_layer) {
                 if (is_out(d.dst)) return fail(Y3_ERR_INVALID, "conv %d: first layer cannot be a head in this mode", o.index);
                 e = bf ? y3::launch_conv_first_bf16(a, c.w_dev, s)
                        : x3 ? y3::launch_conv_first_f32x3(a, c.w_dev, s) : y3::launch_conv_first_f32x2(a, c.w_dev, s);

@@ -62,6 +62,21 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
 // first layer: 3x3 stride-1 conv with Cin=3 (direct, VALU)
 hipError_t launch_conv_first_f32(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
 
+// fused stem (conv_stem.hip): conv0 (3x3/1, 3->32) + conv1 (3x3/2, 32->64), both BN + optional leaky, one launch
+struct StemArgs {
+    const float *img;      // [B,S,S,3] fp32
+    const float *w0;       // conv0 weights [28][32], row k = (u*3 + v)*3 + c, BN scale folded in, row 27 = 0
+    const float *shift0;   // [32]
+    const float *w1;       // conv1 packed [64][288], k = tap*32 + c, BN scale folded in
+    const float *shift1;   // [64]
+    void *dst;             // [B,S/2,S/2,64] fp32
+    int B, S;              // S % 32 == 0
+    int leaky0, leaky1;
+    unsigned img_bytes, dst_bytes;
+    int tiles_y, tiles_x, n_tiles;   // filled by the launcher
+};
+hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s);
+
 // bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
 static constexpr int BF16_TILE_COUNT = 21;
 TileInfo conv_bf16_tile_info(int tile);

@@ -105,6 +105,11 @@ class Net:
         """fp32 conv tile placement on the 8 XCDs: 1 = XCD-blocked order chosen per conv (default), 0 = contiguous runs."""
         check(self.lib.y3_net_set_xcd_mode(self._h, int(mode)), "y3_net_set_xcd_mode")
 
+    def set_stem_fusion(self, on: bool):
+        """conv0 + conv1 as one kernel (default on; applies when the program starts with the Darknet-53 stem and the plan
+        is fp32 without keep_activations)."""
+        check(self.lib.y3_net_set_stem_fusion(self._h, int(bool(on))), "y3_net_set_stem_fusion")
+
     def set_sk_grid(self, workgroups: int):
         """Number of persistent workgroups of the stream-K conv tiles (0 = everything resident at once)."""
         check(self.lib.y3_net_set_sk_grid(self._h, int(workgroups)), "y3_net_set_sk_grid")
