@@ -976,10 +976,16 @@ def test_full_size_608_batch64_properties(rt, program, weights, anchors):
     net.plan(B, S)
     packed, nv = net.detect(x, anchors, 100, 0.5, 0.1)
     assert int(nv.min()) >= 0 and int(nv.max()) <= 100
+    # this plan runs conv0 + conv1 as the fused stem kernel (the keep_activations plan above could not): same network,
+    # conv0 summed in another order -> close to g1, not equal
+    gf = [t.clone() for t in net.forward(x)]
+    for a, b in zip(g1, gf):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+    del g1
     for i in (7, B - 1):                                              # batch independence of the whole pipeline
         gi = net.forward(x[i:i + 1].contiguous())
-        for a, b in zip(g1, gi):
-            assert torch.equal(a[i:i + 1], b)                         # bit for bit: no tile of the classic schedule splits a sum
+        for a, b in zip(gf, gi):
+            assert torch.equal(a[i:i + 1], b)                         # bit for bit: no kernel of the plan splits a sum by batch
         p1, n1 = net.detect(x[i:i + 1].contiguous(), anchors, 100, 0.5, 0.1)
         assert int(n1[0]) == int(nv[i])
         b_a, s_a, c_a, i_a = rt.unpack_detections(packed[i:i + 1])
@@ -1671,3 +1677,44 @@ def test_fused_stem_matches_oracle_and_the_two_launch_form(rt, S, B):
     c1 = net.read_tensor(t1, B).cpu().numpy()
     assert np.abs(c1 - kept[t1]).max() <= 2e-5 * max(1.0, float(np.abs(kept[t1]).max()))
     assert net.profile_convs(xd)[0] > 0.0
+
+
+@pytest.mark.parametrize("S,B", [(32, 1), (64, 3), (416, 2)])
+def test_fused_stem_bf16_matches_oracle_and_the_two_launch_form(rt, S, B):
+    """The bf16 form of the fused stem (config 5): conv0 in fp32 arithmetic rounded to bf16 into the LDS patch, conv1 on
+    the bf16 matrix cores.  conv1's output feeds three linear 1x1 heads whose fp32 outputs are compared (a) with the
+    bf16-emulating oracle under the free-running bar of two bf16 layers (a flipped rounding of one conv0 value moves a
+    conv1 sum by ~2^-8/sqrt(288) of its scale; flipped conv1 roundings move a head sum by ~2^-8/sqrt(64)) and (b) with the
+    two-launch form of the same plan under the same bar; determinism over repeats."""
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    p = mini_program(3, [dict(filters=32, size=3), dict(filters=64, size=3, stride=2)],
+                     [dict(filters=32, size=1, bn=False, act="linear"), dict(filters=32, size=1, bn=False, act="linear"),
+                      dict(filters=64, size=1)])
+    w = synthetic_weights(p, seed=12)
+    x = np.random.default_rng(12).random((B, S, S, 3), dtype=np.float32)
+    ref = O.forward(p, w, x, bf16=True)
+    xd = _cuda(x)
+    outs = {}
+    for fused in (True, False):
+        net = rt.Net(p)
+        net.load_weights(w)
+        net.plan(B, S, _lib.Y3_DTYPE_BF16)
+        net.set_lanes(1)
+        net.set_stem_fusion(fused)
+        got = [g.clone() for g in net.forward(xd)]
+        ms = net.profile_convs(xd)
+        assert (ms[0] == 0.0) == fused
+        outs[fused] = got
+        for r, g in zip(ref, got):
+            g = g.cpu().numpy().reshape(r.shape)
+            scale = max(1.0, float(np.abs(r).max()))
+            assert np.abs(g - r).max() <= 4e-3 * scale and np.abs(g - r).mean() <= 2e-4 * scale, \
+                (fused, float(np.abs(g - r).max()), float(np.abs(g - r).mean()))
+        again = net.forward(xd)
+        assert all(torch.equal(a, b) for a, b in zip(got, again))
+    for a, b in zip(outs[True], outs[False]):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 4e-3 * scale and float((a - b).abs().mean()) <= 2e-4 * scale

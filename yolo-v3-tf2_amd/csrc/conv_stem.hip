@@ -22,7 +22,7 @@
 //          taps, sub-tiles and k chunks with the lane groups of MI355X_MICROARCH.md, LDS section).
 //   w1     64 rows x 288 floats, chunk kc of row n stored at (kc & ~7) | ((kc & 7) ^ ((n >> 1) & 7)).
 //   img    19 x 35 x 3 floats.
-// Summation order per output element: conv0 k = 0, 14, 1, 15, ... (two interleaved halves of the 27 taps x channels);
+// Summation order per output element: conv0 in the step order of stem::k_of_step (pairs of taps x channels);
 // conv1 identical to conv_f32_mfma (tap-major, 8q+t / 8q+4+t).  The order is the same for every pixel of every image.
 #include <type_traits>
 
@@ -42,18 +42,22 @@ constexpr int PATCH_F = PH * PW * C0;     // 17952 floats
 constexpr int W1_F = C1 * K1;             // 18432 floats
 constexpr int IMG_F = IH * IW * 3;        // 1995 floats
 constexpr int NT = 512;
-constexpr int LDS_BYTES = (PATCH_F + W1_F + IMG_F) * 4;
+constexpr int LDS_BYTES = (PATCH_F + W1_F + IMG_F + 1) * 4;
 constexpr int IMG_PER_THREAD = (IMG_F + NT - 1) / NT;   // 4
 
-// float offset inside the image patch of conv0's k-th operand, k = (u*3 + v)*3 + c
-__host__ __device__ constexpr int img_off(int k) { return k < 27 ? ((k / 9) * IW + (k / 3) % 3) * 3 + k % 3 : 0; }
+// (conv0's zero-weight padding operand reads one float past the image patch: the LDS region carries one pad float)
+// conv0's K = 27 (+1 zero) as 14 MFMA steps of two operands (lane halves h = 0 / 1).  Operand k = (u*3 + v)*3 + c sits at
+// float offset 105 u + 3 v + c from the pixel's patch origin: three contiguous runs of nine.  Steps 0..8 pair run 0 with run
+// 1 (offsets s and s + 105), steps 9..13 pair run 2's values i and i + 5 (offsets 210 + i + 5 h; the last step's second
+// operand is the zero-weight pad).  Both halves of a step differ by a constant, so a lane needs TWO address registers
+// (+ immediates) for all 14 reads instead of one per step.
+__host__ __device__ constexpr int k_of_step(int s, int h) { return s < 9 ? (h ? 9 + s : s) : (h ? (s == 13 ? 27 : 14 + s) : 9 + s); }
 }  // namespace stem
 
 __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
 {
     using namespace stem;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *patch = smem;
     float *w1s = smem + PATCH_F;
     float *imgs = smem + PATCH_F + W1_F;
 
@@ -65,17 +69,13 @@ __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
     // ---- once per workgroup: conv1 weights into LDS (swizzled), conv0 weight fragments and shifts into registers ----
     for (int g = tid; g < C1 * (K1 / 4); g += NT) {
         const int n = g / (K1 / 4), kc = g - n * (K1 / 4);
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(p.w1 + n * K1 + kc * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(p.w1) + n * K1 + kc * 4);
         const int kp = (kc & ~7) | ((kc & 7) ^ ((n >> 1) & 7));
         *reinterpret_cast<f32x4 *>(w1s + n * K1 + kp * 4) = v;
     }
-    float b0[14];            // conv0 B fragments: lane (n = fr, half fh) holds w0[k = s + 14*fh][n]
-    int d0[14];              // byte offset of operand k = s + 14*fh inside the image patch
+    float b0[14];            // conv0 B fragments: lane (n = fr, half fh) holds w0[k_of_step(s, fh)][n]
 #pragma unroll
-    for (int s = 0; s < 14; ++s) {
-        b0[s] = p.w0[(s + 14 * fh) * C0 + fr];
-        d0[s] = (fh ? img_off(s + 14) : img_off(s)) * 4;
-    }
+    for (int s = 0; s < 14; ++s) b0[s] = p.w0[(fh ? k_of_step(s, 1) : k_of_step(s, 0)) * C0 + fr];
     const float sh0 = p.shift0[fr];
     // phase-2 role of this wave: rows [2*wm, 2*wm + 2) of the tile x channels [32*wn, +32)
     const int wm = wave >> 1, wn = wave & 1;
@@ -84,10 +84,9 @@ __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
     // ---- per-lane address pieces (all loop invariant) ----
     // phase 1, row sub-tiles: this wave computes patch rows y = 2*wave and 2*wave + 1 (wave 0 also row 16), 32 pixels
     // x = 0..31 each (lane row = fr); wave 1 also the column x = 32 (17 pixels, lane row = y).
-    // A operand: image patch float ((y + u)*IW + x + v)*3 + c  ->  per lane (fr*3)*4 + d0[s], rows by immediates.
-    int a1[14];
-#pragma unroll
-    for (int s = 0; s < 14; ++s) a1[s] = (2 * wave * IW * 3 + fr * 3) * 4 + d0[s];
+    // A operand: image patch float (y*IW + x)*3 + offset(step, half): two per-lane registers, steps and rows by immediates.
+    const int a1lo = (PATCH_F + W1_F + 2 * wave * IW * 3 + fr * 3 + 105 * fh) * 4;        // steps 0..8:  + s*4
+    const int a1hi = (PATCH_F + W1_F + 2 * wave * IW * 3 + fr * 3 + 210 + 5 * fh) * 4;    // steps 9..13: + (s - 9)*4
     // phase 1 write: accumulator element e of lane (fr = channel n, fh): pixel x = xe + 4*fh, xe = (e & 3) + 8*(e >> 2).
     //   index = y*33 + (x >> 1) + (x & 1)*17 = y*33 + 2*fh + [(xe >> 1) + (xe & 1)*17]
     //   chunk = (n >> 2) ^ (((x >> 1) + (y >> 1)) & 7) = (n >> 2) ^ ((ce + 2*fh + wave) & 7), ce = xe >> 1, y >> 1 == wave
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
             float a[14];
 #pragma unroll
             for (int s = 0; s < 14; ++s)
-                a[s] = *reinterpret_cast<const float *>(lds + (PATCH_F + W1_F) * 4 + a1[s] + YD * IW * 3 * 4);
+                a[s] = *reinterpret_cast<const float *>(lds + (s < 9 ? a1lo + s * 4 : a1hi + (s - 9) * 4) + YD * IW * 3 * 4);
 #pragma unroll
             for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc, 0, 0, 0);
             const int y = 2 * wave + YD;
@@ -201,10 +200,11 @@ __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
             const int yl = fr < PH ? fr : PH - 1;
-            const int abase = (PATCH_F + W1_F) * 4 + ((yl * IW + 32) * 3) * 4;
+            const int abase = (PATCH_F + W1_F + (yl * IW + 32) * 3) * 4;
             float a[14];
 #pragma unroll
-            for (int s = 0; s < 14; ++s) a[s] = *reinterpret_cast<const float *>(lds + abase + d0[s]);
+            for (int s = 0; s < 14; ++s)
+                a[s] = *reinterpret_cast<const float *>(lds + abase + (s < 9 ? (105 * fh + s) * 4 : (210 + 5 * fh + s - 9) * 4));
 #pragma unroll
             for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc, 0, 0, 0);
 #pragma unroll
@@ -288,6 +288,252 @@ hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s)
     }
     const int grid = p.n_tiles < cus[dev] ? p.n_tiles : cus[dev];   // one persistent workgroup per CU
     hipLaunchKernelGGL(conv_stem_f32, dim3(grid), dim3(NT), LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// bf16 variant (BASELINE config 5): same tiling and phase structure.  conv0 stays in fp32 arithmetic on the fp32 matrix
+// cores (like the stand-alone bf16 first-layer launch: fp32 image, fp32 weights, y = acc*scale + shift, leaky) and its
+// result is rounded to bf16 exactly where the two-launch form stores it -- here into the LDS patch; conv1 runs on
+// v_mfma_f32_32x32x16_bf16 from LDS (bf16 weights, unscaled; y = acc*scale + shift, leaky, bf16 out).
+// LDS: patch 561 x 64 B (chunk c of pixel (y, x) at c ^ ((x >> 2) & 3)), w1 64 x 576 B (chunk c of a tap's four at
+// c ^ ((n >> 2) & 3)), image patch 7,980 B: 80,748 B -> TWO workgroups per CU, one computing while the other stores.
+// The output tile leaves through LDS (the patch region, dead after phase 2): every store instruction writes whole
+// 128-B pixels (64 channels x 2 B), 16 pixels of a row contiguous.
+// -----------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
+namespace stemb {
+using namespace stem;
+constexpr int PATCH_B = PH * PW * C0 * 2;     // 35904 bytes
+constexpr int W1_B = C1 * K1 * 2;             // 36864 bytes
+constexpr int IMG_B = (IMG_F + 1) * 4;        // 7984 bytes (one pad float: conv0's zero-weight operand)
+constexpr int LDS_BYTES_B = PATCH_B + W1_B + IMG_B;   // 80752 <= 81920: two workgroups per CU
+}  // namespace stemb
+
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+
+__global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
+{
+    using namespace stemb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    char *lds = reinterpret_cast<char *>(smemb);
+    float *imgs = reinterpret_cast<float *>(smemb + PATCH_B + W1_B);
+
+    // conv1 weights (bf16 [64][288]) into LDS: 16-B chunk kc (8 channels; 4 chunks per tap) of row n
+    {
+        const unsigned short *w1 = static_cast<const unsigned short *>(p.w1);
+        for (int g = tid; g < C1 * (K1 / 8); g += NT) {
+            const int n = g / (K1 / 8), kc = g - n * (K1 / 8);
+            const u32x4s v = *reinterpret_cast<const u32x4s *>(w1 + n * K1 + kc * 8);
+            const int kp = (kc & ~3) | ((kc & 3) ^ ((n >> 2) & 3));
+            *reinterpret_cast<u32x4s *>(lds + PATCH_B + n * (K1 * 2) + kp * 16) = v;
+        }
+    }
+    float b0[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) b0[s] = p.w0[(fh ? k_of_step(s, 1) : k_of_step(s, 0)) * C0 + fr];
+    const float sc0 = p.scale0[fr], sh0 = p.shift0[fr];
+    const int wm = wave >> 1, wn = wave & 1;
+    const float sc1 = p.scale1[wn * 32 + fr], sh1 = p.shift1[wn * 32 + fr];
+
+    const int a1lo = PATCH_B + W1_B + (2 * wave * IW * 3 + fr * 3 + 105 * fh) * 4;
+    const int a1hi = PATCH_B + W1_B + (2 * wave * IW * 3 + fr * 3 + 210 + 5 * fh) * 4;
+    // phase 1 write: element e -> pixel x = xe + 4 fh of row y; channel n = fr: chunk (n >> 3) ^ (((xe >> 2) + fh) & 3)
+    int xr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xr[k] = (((fr >> 3) ^ ((k + fh) & 3)) << 4) + (fr & 7) * 2;
+    // phase 2 A: pixel (r = 2 wm + (fr >> 4), c = fr & 15), tap (u, v): x = 2c + v, key (x >> 2) & 3 =
+    // ((c >> 1) + ((c & 1) & (v >> 1))) & 3 -> two variants (v < 2, v == 2)
+    const int pr = 2 * wm + (fr >> 4), pc = fr & 15;
+    int a2[2][2];
+#pragma unroll
+    for (int vk = 0; vk < 2; ++vk)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            a2[vk][s] = (66 * pr + pc) * 64 + (((2 * s + fh) ^ (((pc >> 1) + ((pc & 1) & vk)) & 3)) << 4);
+    int bw[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) bw[s] = PATCH_B + (wn * 32 + fr) * (K1 * 2) + (((2 * s + fh) ^ (((wn * 32 + fr) >> 2) & 3)) << 4);
+
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.img), 0, p.img_bytes, 0x00020000);
+    const int S = p.S, So = p.S >> 1;
+    const int tiles_per_img = p.tiles_y * p.tiles_x;
+
+    auto img_voff = [&](int tile, unsigned (&vo)[IMG_PER_THREAD]) {
+        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
+        const int ty = t2 / p.tiles_x, tx = t2 - ty * p.tiles_x;
+        const int iy0 = 2 * ty * TH - 2, ix0 = 2 * tx * TW - 2;
+#pragma unroll
+        for (int i = 0; i < IMG_PER_THREAD; ++i) {
+            const int e = tid + i * NT;
+            const int iy = e / (IW * 3), rem = e - iy * (IW * 3);
+            const int ix = rem / 3, c = rem - ix * 3;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            const bool ok = e < IMG_F && (unsigned)gy < (unsigned)S && (unsigned)gx < (unsigned)S;
+            vo[i] = ok ? (unsigned)(((b * S + gy) * S + gx) * 3 + c) * 4u : p.img_bytes;
+        }
+    };
+    float rimg[IMG_PER_THREAD];
+    auto img_fetch = [&](const unsigned (&vo)[IMG_PER_THREAD]) {
+#pragma unroll
+        for (int i = 0; i < IMG_PER_THREAD; ++i)
+            rimg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, (int)vo[i], 0, 0));
+    };
+    auto img_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < IMG_PER_THREAD; ++i)
+            if (tid + i * NT < IMG_F) imgs[tid + i * NT] = rimg[i];
+    };
+
+    int tile = blockIdx.x;
+    if (tile < p.n_tiles) {
+        unsigned vo[IMG_PER_THREAD];
+        img_voff(tile, vo);
+        img_fetch(vo);
+        img_stage();
+    }
+    __syncthreads();
+
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img, t2 = tile - b * tiles_per_img;
+        const int ty = t2 / p.tiles_x, tx = t2 - ty * p.tiles_x;
+
+        // ---- phase 1: conv0 (fp32 MFMA) -> bf16 patch ----
+        auto conv0_row = [&](auto ytag) {
+            constexpr int YD = decltype(ytag)::value;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            float a[14];
+#pragma unroll
+            for (int s = 0; s < 14; ++s)
+                a[s] = *reinterpret_cast<const float *>(lds + (s < 9 ? a1lo + s * 4 : a1hi + (s - 9) * 4) + YD * IW * 3 * 4);
+#pragma unroll
+            for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc, 0, 0, 0);
+            const int y = 2 * wave + YD;
+            const bool zrow = (ty == 0) && (y == 0);
+            const int base = (y * PW + 2 * fh) * 64;
+            int wa[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wa[k] = base + xr[k];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int xe = (e & 3) + 8 * (e >> 2);
+                float v = acc[e] * sc0 + sh0;
+                if (p.leaky0) v = fmaxf(v, 0.1f * v);
+                const bool zero = zrow || (tx == 0 && xe == 0 && fh == 0);
+                v = zero ? 0.0f : v;
+                const int imm = ((xe >> 1) + (xe & 1) * 17) * 64;
+                *reinterpret_cast<unsigned short *>(lds + wa[(xe >> 2) & 3] + imm) = bf16_bits(v);
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I16 = std::integral_constant<int, 16>;
+        conv0_row(I0{});
+        conv0_row(I1{});
+        if (wave == 0) conv0_row(I16{});
+        if (wave == 1) {   // column x = 32: lane row = patch row y
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            const int yl = fr < PH ? fr : PH - 1;
+            const int abase = PATCH_B + W1_B + ((yl * IW + 32) * 3) * 4;
+            float a[14];
+#pragma unroll
+            for (int s = 0; s < 14; ++s)
+                a[s] = *reinterpret_cast<const float *>(lds + abase + (s < 9 ? (105 * fh + s) * 4 : (210 + 5 * fh + s - 9) * 4));
+#pragma unroll
+            for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int y = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                float v = acc[e] * sc0 + sh0;
+                if (p.leaky0) v = fmaxf(v, 0.1f * v);
+                v = (ty == 0 && y == 0) ? 0.0f : v;
+                // x = 32: index y*33 + 16, key (32 >> 2) & 3 = 0
+                const int off = (y * PW + 16) * 64 + ((fr >> 3) << 4) + (fr & 7) * 2;
+                if (y < PH) *reinterpret_cast<unsigned short *>(lds + off) = bf16_bits(v);
+            }
+        }
+        __syncthreads();   // (1) patch complete, image patch free
+
+        const int next = tile + gridDim.x;
+        if (next < p.n_tiles) {
+            unsigned vo[IMG_PER_THREAD];
+            img_voff(next, vo);
+            img_fetch(vo);
+        }
+
+        // ---- phase 2: conv1 on the bf16 matrix cores, everything from LDS ----
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int aimm = (33 * u + (v >> 1) + 17 * (v & 1)) * 64;
+                const int bimm = (u * 3 + v) * 64;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(lds + a2[v >> 1][s] + aimm);
+                    const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(lds + bw[s] + bimm);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+                }
+            }
+        __syncthreads();   // (2) every wave is done reading the patch: it becomes the output staging tile
+
+        // ---- epilogue: [128 pixels][64 channels] bf16 through LDS, then whole 128-B pixels to HBM ----
+        {
+            const int n = wn * 32 + fr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * fh;      // pixel of this wave's 32
+                float v = acc[e] * sc1 + sh1;
+                if (p.leaky1) v = fmaxf(v, 0.1f * v);
+                *reinterpret_cast<unsigned short *>(lds + (wm * 32 + m) * 128 + n * 2) = bf16_bits(v);
+            }
+        }
+        __syncthreads();   // (3) staging tile complete
+        {
+            unsigned short *dst = static_cast<unsigned short *>(p.dst);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int g = tid + i * NT;                         // 1024 chunks of 16 B
+                const int P = g >> 3, ch = g & 7;
+                const u32x4s v = *reinterpret_cast<const u32x4s *>(lds + P * 128 + ch * 16);
+                const int oy = ty * TH + (P >> 4), ox = tx * TW + (P & 15);
+                *reinterpret_cast<u32x4s *>(dst + ((size_t)(b * So + oy) * So + ox) * C1 + ch * 8) = v;
+            }
+        }
+        if (next < p.n_tiles) img_stage();
+        __syncthreads();   // (4) staging tile read, next image patch in place
+    }
+}
+
+hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s)
+{
+    using namespace stemb;
+    if (a.S % 32 || a.B <= 0 || !a.img || !a.w0 || !a.w1 || !a.dst || !a.scale0 || !a.scale1) return hipErrorInvalidValue;
+    StemArgs p = a;
+    p.tiles_y = (a.S / 2) / TH;
+    p.tiles_x = (a.S / 2) / TW;
+    p.n_tiles = a.B * p.tiles_y * p.tiles_x;
+    static LdsAttrOnce attr;
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv_stem_bf16), LDS_BYTES_B); e != hipSuccess) return e;
+    int dev = 0, cus = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+    if (cus <= 0) cus = 256;
+    const int grid = p.n_tiles < 2 * cus ? p.n_tiles : 2 * cus;   // two persistent workgroups per CU
+    hipLaunchKernelGGL(conv_stem_bf16, dim3(grid), dim3(NT), LDS_BYTES_B, s, p);
     return hipGetLastError();
 }
 

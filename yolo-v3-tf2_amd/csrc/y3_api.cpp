@@ -71,7 +71,8 @@ struct ConvSlot {
     bool x2_ok = true;         // false: a BN-scaled weight is outside the fp16 range, the two-plane mode cannot be planned
     void *wx2_dev = nullptr;   // packed [CoutPad64][2 planes][K] fp16 (h, l' = (w - h) * 2^11 of the BN-scaled weights)
     float *w_dev = nullptr;    // packed [CoutPad][K] (or HWIO for the first layer)
-    float *w0stem_dev = nullptr;   // first layer only: [28][Cout] = HWIO rows x BN scale, row 27 zero (fused stem kernel)
+    float *w0stem_dev = nullptr;   // first layer only: [28][Cout] = HWIO rows x BN scale, row 27 zero (fused stem kernel, fp32)
+    float *w0raw_dev = nullptr;    // first layer only: the same without the scale (fused stem kernel, bf16 mode)
     void *wbf_dev = nullptr;   // same, bf16 (not for the first layer)
     float *scale_dev = nullptr;
     float *shift_dev = nullptr;
@@ -327,7 +328,8 @@ int choose_tile(const ConvSlot &c, long long M)
 // else reads conv0's output, and the plan is fp32 with every intermediate reusable: the pair runs as csrc/conv_stem.hip.
 static bool stem_applicable(const y3_net *net)
 {
-    if (net->dtype != Y3_DTYPE_F32 || net->keep_all || net->image_size % 32 || net->early_ops > 0) return false;
+    if ((net->dtype != Y3_DTYPE_F32 && net->dtype != Y3_DTYPE_BF16) || net->keep_all || net->image_size % 32 || net->early_ops > 0)
+        return false;
     if (net->ops.size() < 2 || net->ops[0].kind != 0 || net->ops[1].kind != 0) return false;
     const ConvSlot &c0 = net->convs[net->ops[0].index], &c1 = net->convs[net->ops[1].index];
     const y3_conv_desc &a = c0.d, &b = c1.d;
@@ -450,6 +452,7 @@ void y3_net_destroy(y3_net *net)
     for (ConvSlot &c : net->convs) {
         if (c.w_dev) (void)hipFree(c.w_dev);
         if (c.w0stem_dev) (void)hipFree(c.w0stem_dev);
+        if (c.w0raw_dev) (void)hipFree(c.w0raw_dev);
         if (c.wbf_dev) (void)hipFree(c.wbf_dev);
         if (c.wx3_dev) (void)hipFree(c.wx3_dev);
         if (c.wx2_dev) (void)hipFree(c.wx2_dev);
@@ -508,6 +511,10 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
             for (int n = 0; n < d.cout; ++n) w28[(size_t)k * d.cout + n] = w[(size_t)k * d.cout + n] * scale[n];
         if (!c.w0stem_dev) HIP_TRY(hipMalloc(&c.w0stem_dev, w28.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c.w0stem_dev, w28.data(), w28.size() * sizeof(float), hipMemcpyHostToDevice));
+        for (int k = 0; k < K; ++k)
+            for (int n = 0; n < d.cout; ++n) w28[(size_t)k * d.cout + n] = w[(size_t)k * d.cout + n];
+        if (!c.w0raw_dev) HIP_TRY(hipMalloc(&c.w0raw_dev, w28.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(c.w0raw_dev, w28.data(), w28.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (!c.first_layer) {
         std::vector<unsigned short> pb(pk.size());
@@ -962,9 +969,11 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 const ConvSlot &c0 = net->convs[net->ops[0].index];
                 y3::StemArgs sa{};
                 sa.img = static_cast<const float *>(ptr(c0.d.src0));
-                sa.w0 = c0.w0stem_dev;
+                sa.w0 = bf ? c0.w0raw_dev : c0.w0stem_dev;
+                sa.scale0 = c0.scale_dev;
                 sa.shift0 = c0.shift_dev;
-                sa.w1 = c.w_dev;
+                sa.w1 = bf ? c.wbf_dev : static_cast<const void *>(c.w_dev);
+                sa.scale1 = c.scale_dev;
                 sa.shift1 = c.shift_dev;
                 sa.dst = a.dst;
                 sa.B = nb;
@@ -973,7 +982,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 sa.leaky1 = d.leaky;
                 sa.img_bytes = (unsigned)bytes(c0.d.src0);
                 sa.dst_bytes = a.dst_bytes;
-                e = y3::launch_conv_stem_f32(sa, s);
+                e = bf ? y3::launch_conv_stem_bf16(sa, s) : y3::launch_conv_stem_f32(sa, s);
             } else if ((bf || x3 || x2) && c.first_layer) {
                 if (is_out(d.dst)) return fail(Y3_ERR_INVALID, "conv %d: first layer cannot be a head in this mode", o.index);
                 e = bf ? y3::launch_conv_first_bf16(a, c.w_dev, s)

@@ -65,17 +65,20 @@ hipError_t launch_conv_first_f32(const ConvArgs &a, const float *w_hwio_dev, hip
 // fused stem (conv_stem.hip): conv0 (3x3/1, 3->32) + conv1 (3x3/2, 32->64), both BN + optional leaky, one launch
 struct StemArgs {
     const float *img;      // [B,S,S,3] fp32
-    const float *w0;       // conv0 weights [28][32], row k = (u*3 + v)*3 + c, BN scale folded in, row 27 = 0
+    const float *w0;       // conv0 weights [28][32] fp32, row k = (u*3 + v)*3 + c, row 27 = 0 (fp32 kernel: BN scale folded in)
+    const float *scale0;   // [32]  (bf16 kernel only: y = acc*scale + shift like the stand-alone bf16 launches)
     const float *shift0;   // [32]
-    const float *w1;       // conv1 packed [64][288], k = tap*32 + c, BN scale folded in
+    const void *w1;        // conv1 packed [64][288], k = tap*32 + c: fp32 with the BN scale folded in / bf16 unscaled
+    const float *scale1;   // [64]  (bf16 kernel only)
     const float *shift1;   // [64]
-    void *dst;             // [B,S/2,S/2,64] fp32
+    void *dst;             // [B,S/2,S/2,64] fp32 / bf16
     int B, S;              // S % 32 == 0
     int leaky0, leaky1;
     unsigned img_bytes, dst_bytes;
     int tiles_y, tiles_x, n_tiles;   // filled by the launcher
 };
 hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s);
+hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s);   // conv0 in fp32 arithmetic, bf16 patch, conv1 on bf16 MFMA
 
 // bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
 static constexpr int BF16_TILE_COUNT = 21;
