@@ -73,63 +73,6 @@ def parity_gate(program, weights, anchors, images_host, device_out, n, M, iou, s
     return out
 
 
-class SclkSampler:
-    """Shader clock of the busy GPU while the timed region runs, read from sysfs every 20 ms (hwmon freq1_input, else
-    the starred line of pp_dpm_sclk).  The roofline peak assumes 2400 MHz; the chip holds less under this load
-    (power cap), so the line also carries the fraction of the peak at the clock it really ran at.  None when the box
-    exposes neither file."""
-
-    def __init__(self):
-        import glob
-        self.src = []
-        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
-            hw = sorted(glob.glob(os.path.join(card, "hwmon/hwmon*/freq1_input")))
-            if os.path.exists(os.path.join(card, "pp_dpm_sclk")):     # what rocm-smi --showclocks reports
-                self.src.append(("dpm", os.path.join(card, "pp_dpm_sclk")))
-            elif hw:
-                self.src.append(("hz", hw[0]))
-        self.samples = [[] for _ in self.src]
-        self._stop = None
-        self._th = None
-
-    def _read(self, kind, path):
-        try:
-            txt = open(path).read()
-            if kind == "hz":
-                return float(txt) / 1e6
-            for ln in txt.splitlines():
-                if ln.rstrip().endswith("*"):
-                    return float("".join(c for c in ln.split(":")[1] if c.isdigit() or c == "."))
-        except (OSError, ValueError, IndexError):
-            return None
-        return None
-
-    def start(self):
-        import threading
-        if not self.src:
-            return
-        self._stop = threading.Event()
-
-        def loop():
-            while not self._stop.is_set():
-                for i, (k, p) in enumerate(self.src):
-                    v = self._read(k, p)
-                    if v:
-                        self.samples[i].append(v)
-                self._stop.wait(0.02)
-        self._th = threading.Thread(target=loop, daemon=True)
-        self._th.start()
-
-    def stop(self):
-        """-> (mean MHz of the busiest card, number of samples) or (None, 0)"""
-        if self._th is None:
-            return None, 0
-        self._stop.set()
-        self._th.join()
-        means = [(sum(v) / len(v), len(v)) for v in self.samples if v]
-        return max(means) if means else (None, 0)
-
-
 def host_cpu_share():
     """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands one GPU's
     share of a 256-thread host to the job; running 256 threads on it thrashes)."""
@@ -353,9 +296,6 @@ def main():
             out = step()
         graph.replay()
     fence()
-    sclk = SclkSampler() if rank == 0 else None
-    if sclk:
-        sclk.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if graph is not None:
@@ -364,7 +304,16 @@ def main():
             out = step(i)
     fence()
     dt = time.perf_counter() - t0
-    sclk_mhz, sclk_n = sclk.stop() if sclk else (None, 0)
+    # shader clock under this load, measured in-kernel after the timed region (sysfs / rocm-smi report the DPM level, not
+    # the clock the chip holds at its power cap): ~1 s of forwards back to back, the last one's stem kernel is stamped
+    sclk_mhz, sclk_src = None, None
+    if rank == 0:
+        try:
+            sclk_mhz = net.measure_sclk(images, grids, forwards=max(10, int(1000.0 / max(1.0, dt / args.steps * 1e3))))
+            sclk_src = ("s_memtime / s_memrealtime stamps inside the largest conv launch after ~1 s of back-to-back forwards "
+                        "(y3_net_measure_sclk; sysfs and rocm-smi report the DPM level, not the clock held at the power cap)")
+        except runtime.Y3Error as e:
+            sclk_src = f"not measured: {e}"
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -457,7 +406,7 @@ def main():
                 "bound": "mfma", "kernel": f"conv stack (74 x conv_{'f32x3' if args.dtype == 'f32x2' else args.dtype}_mfma{'<2 planes>' if args.dtype == 'f32x2' else ''} launches + 1 first-layer conv per step)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved * mfma_flops_factor / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None, "sclk_samples": sclk_n,
+                "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None, "sclk_source": sclk_src,
                 "frac_of_clock_limited_peak": (round(achieved * mfma_flops_factor / (peak * sclk_mhz / 2400.0), 4)
                                                if sclk_mhz else None),
                 "issued_over_algorithmic_flops": mfma_flops_factor,

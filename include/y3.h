@@ -137,6 +137,13 @@ y3_status y3_net_keep_activations(y3_net *net, int keep);
  * run as ONE kernel that keeps conv0's output (the largest tensor of the network, 1.4 GB at 64 x 416^2) in LDS.
  * 0: one launch per conv.  Results agree to fp32 rounding (conv0's summation order differs between the two kernels). */
 y3_status y3_net_set_stem_fusion(y3_net *net, int on);
+/* Measurement aid (bench.py): the shader clock the chip holds under this network's load.  Runs `forwards` forwards back to
+ * back (grids_dev as for y3_net_forward); in the last one, thread 0 of the middle workgroup of the conv with the most FLOPs (fp32
+ * plans: an MFMA conv launch; bf16 plans: the fused stem kernel) reads s_memtime and s_memrealtime at its entry and after
+ * its epilogue: MHz = d(memtime) / d(memrealtime) x 100 (MI355X_MICROARCH.md, DVFS give-back item 6).  Synchronises the
+ * stream.  No product launch carries stamps (the kernels test a null pointer). */
+y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
+                              float *mhz_out, void *stream);
 /* Before y3_net_plan: run the first n_convs convs chunk_images images at a time, then the rest of the network on the
  * whole batch.  The first layers' activations are the largest tensors of the network (1.4 GB for 64 images at 416x416);
  * in chunks they are still in the Infinity Cache when the next conv reads them.  Results are unchanged (images are

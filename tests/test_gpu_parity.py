@@ -1449,6 +1449,8 @@ def test_backbone_only_config2(rt, program, weights):
     # config-2 geometry
     B, S = 32, 416
     xb = torch.rand((B, S, S, 3), generator=torch.Generator(device="cuda").manual_seed(3), device="cuda")
+    net.plan(B, S)
+    net.set_stem_fusion(False)   # the keep_activations plan below runs conv0 and conv1 as two launches: same kernels here
     outs = [t.clone() for t in net.forward(xb)]
     full = rt.Net(program)
     full.load_weights(weights)
@@ -1718,3 +1720,21 @@ def test_fused_stem_bf16_matches_oracle_and_the_two_launch_form(rt, S, B):
     for a, b in zip(outs[True], outs[False]):
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 4e-3 * scale and float((a - b).abs().mean()) <= 2e-4 * scale
+
+
+def test_measure_sclk_reads_a_plausible_clock(rt, program, weights):
+    """y3_net_measure_sclk: the in-kernel stamp pair of the fused stem kernel gives a clock between the chip's idle and
+    maximum frequency, leaves the results of a forward untouched, and refuses a plan without the stem kernel."""
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(8, 96)
+    x = torch.rand((8, 96, 96, 3), device="cuda")
+    g = [t.clone() for t in net.forward(x)]
+    mhz = net.measure_sclk(x, [torch.empty_like(t) for t in g], forwards=20)
+    assert 100.0 < mhz < 2600.0, mhz
+    assert all(torch.equal(a, b) for a, b in zip(g, net.forward(x)))
+    from yolo_v3_tf2_amd import _lib
+    net.plan(8, 96, _lib.Y3_DTYPE_BF16)
+    net.set_stem_fusion(False)      # a bf16 plan without the stem kernel has no launch that carries stamps
+    with pytest.raises(rt.Y3Error, match="stamps"):
+        net.measure_sclk(x, g, forwards=2)

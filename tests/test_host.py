@@ -135,29 +135,3 @@ def test_bench_host_helpers(monkeypatch):
     monkeypatch.setenv("Y3_CPU_THREADS", "1")
     assert bench.host_cpu_share() == 1
 
-
-def test_bench_clock_sampler(tmp_path):
-    """bench.py's shader-clock sampler: reads hwmon freq1_input (Hz) or the starred pp_dpm_sclk line, reports the
-    busiest card's mean, and degrades to (None, 0) when the box exposes neither."""
-    import importlib.util
-    import os
-    import time
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("y3_bench2", os.path.join(root, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    s = bench.SclkSampler()
-    hz, dpm = tmp_path / "freq1_input", tmp_path / "pp_dpm_sclk"
-    hz.write_text("2315000000\n")
-    dpm.write_text("0: 132Mhz\n1: 2100Mhz *\n")
-    assert abs(s._read("hz", str(hz)) - 2315.0) < 1e-6 and abs(s._read("dpm", str(dpm)) - 2100.0) < 1e-6
-    assert s._read("hz", str(tmp_path / "missing")) is None
-    s.src, s.samples = [("hz", str(hz)), ("dpm", str(dpm))], [[], []]
-    s.start()
-    time.sleep(0.1)
-    mhz, n = s.stop()
-    assert abs(mhz - 2315.0) < 1e-6 and n >= 2
-    e = bench.SclkSampler()
-    e.src, e.samples = [], []
-    e.start()
-    assert e.stop() == (None, 0)

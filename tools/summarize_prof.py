@@ -32,7 +32,7 @@ def short(name):
     m = re.search(r"conv_first_f32x3<\d+, (\d)>", name)
     if m:
         return f"conv_first_f32x{m.group(1)}"
-    for k in ("conv_first_f32x3", "conv_first_f32", "conv_first_bf16", "decode_kernel", "nms_kernel", "pack_kernel", "class_scores"):
+    for k in ("conv_stem_f32", "conv_stem_bf16", "conv_first_f32x3", "conv_first_f32", "conv_first_bf16", "decode_kernel", "nms_kernel", "pack_kernel", "class_scores"):
         if k in name:
             return k
     return name[:60]
@@ -97,7 +97,7 @@ def main(out):
     if agg:
         import json
         conv = [k for k in agg if k.startswith("conv_")]
-        first = [k for k in conv if "first" in k]
+        first = [k for k in conv if "first" in k or "stem" in k]   # launched once per step
         steps = max(calls[k] for k in first) if first else 1
         fetch = sum(agg[k].get("FETCH_SIZE", 0) for k in conv) * 1024 * 2 / steps
         write = sum(agg[k].get("WRITE_SIZE", 0) for k in conv) * 1024 / steps

@@ -109,6 +109,7 @@ SYMBOLS = {
     "y3_net_set_sk_grid": (_i, [_vp, _i]),
     "y3_net_set_xcd_mode": (_i, [_vp, _i]),
     "y3_net_set_stem_fusion": (_i, [_vp, _i]),
+    "y3_net_measure_sclk": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _fp, _vp]),
     "y3_net_plan": (_i, [_vp, _i, _i, _i]),
     "y3_net_forward": (_i, [_vp, _vp, _i, C.POINTER(_vp), _vp]),
     "y3_net_read_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_sz), _vp]),

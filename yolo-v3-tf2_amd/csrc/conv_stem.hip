@@ -54,8 +54,19 @@ constexpr int IMG_PER_THREAD = (IMG_F + NT - 1) / NT;   // 4
 __host__ __device__ constexpr int k_of_step(int s, int h) { return s < 9 ? (h ? 9 + s : s) : (h ? (s == 13 ? 27 : 14 + s) : 9 + s); }
 }  // namespace stem
 
+
+// shader-clock stamps (measurement launches only: StemArgs.clk_stamps != nullptr)
+__device__ __forceinline__ void stem_stamp(unsigned long long *out, int slot)
+{
+    if (out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        out[slot] = __builtin_amdgcn_s_memtime();
+        out[slot + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
 {
+    stem_stamp(p.clk_stamps, 0);
     using namespace stem;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *w1s = smem + PATCH_F;
@@ -143,6 +154,9 @@ __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
             if (tid + i * NT < IMG_F) imgs[tid + i * NT] = rimg[i];
     };
 
+    // the zero-weight 28th operand of conv0 reads one float past the image patch for the patch's last pixel: it must be
+    // a finite number (0 x NaN would poison the sum), so the pad float is cleared once
+    if (tid == 0) imgs[IMG_F] = 0.0f;
     int tile = blockIdx.x;
     if (tile < p.n_tiles) {
         unsigned vo[IMG_PER_THREAD];
@@ -265,6 +279,7 @@ __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
         if (next < p.n_tiles) img_stage();
         __syncthreads();   // patch free for the next tile; its image patch is in place
     }
+    stem_stamp(p.clk_stamps, 2);
 }
 
 hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s)
@@ -316,6 +331,7 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_
 
 __global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
 {
+    stem_stamp(p.clk_stamps, 0);
     using namespace stemb;
     extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
     const int tid = threadIdx.x;
@@ -391,6 +407,9 @@ __global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
             if (tid + i * NT < IMG_F) imgs[tid + i * NT] = rimg[i];
     };
 
+    // the zero-weight 28th operand of conv0 reads one float past the image patch for the patch's last pixel: it must be
+    // a finite number (0 x NaN would poison the sum), so the pad float is cleared once
+    if (tid == 0) imgs[IMG_F] = 0.0f;
     int tile = blockIdx.x;
     if (tile < p.n_tiles) {
         unsigned vo[IMG_PER_THREAD];
@@ -516,6 +535,7 @@ __global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
         if (next < p.n_tiles) img_stage();
         __syncthreads();   // (4) staging tile read, next image patch in place
     }
+    stem_stamp(p.clk_stamps, 2);
 }
 
 hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s)

@@ -119,6 +119,8 @@ struct y3_net {
     int sk_cnt_cap = 0;
     int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 as one kernel when the graph allows it
     bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
+    unsigned long long *clk_stamps = nullptr;   // y3_net_measure_sclk: device buffer one conv launch stamps into (else null)
+    int clk_conv = -1;                          // ... and which conv
     int xcd_mode = 1;              // y3_net_set_xcd_mode: 0 contiguous tile runs per XCD, 1 XCD-blocked order chosen per conv
     int sk_grid = 0;               // y3_net_set_sk_grid: > 0 overrides the number of persistent workgroups (tests)
     int cur_batch = 1;             // batch of the forward being enqueued
@@ -958,6 +960,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.sk_cnt_cap = net->sk_cnt_cap;
             a.sk_grid_override = net->sk_grid;
             a.xcd_gn = 0;
+            a.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : nullptr;   // fp32 MFMA kernel and stem only
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if (net->stem_fused && oi == 0) {       // conv0 runs inside conv1's launch (fused stem)
                 if (ms_out && o.index < n_ms) ms_out[o.index] = 0.0f;
@@ -982,6 +985,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 sa.leaky1 = d.leaky;
                 sa.img_bytes = (unsigned)bytes(c0.d.src0);
                 sa.dst_bytes = a.dst_bytes;
+                sa.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : nullptr;
                 e = bf ? y3::launch_conv_stem_bf16(sa, s) : y3::launch_conv_stem_f32(sa, s);
             } else if ((bf || x3 || x2) && c.first_layer) {
                 if (is_out(d.dst)) return fail(Y3_ERR_INVALID, "conv %d: first layer cannot be a head in this mode", o.index);
@@ -1138,6 +1142,47 @@ y3_status y3_net_profile_convs(y3_net *net, const float *images_dev, int batch, 
     (void)hipStreamSynchronize((hipStream_t)stream);
     for (int i = 0; i < 3; ++i) (void)hipFree(g[i]);
     return st;
+}
+
+y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
+                              float *mhz_out, void *stream)
+{
+    if (!net || !mhz_out || forwards < 1) return fail(Y3_ERR_INVALID, "y3_net_measure_sclk: bad argument");
+    // the launch that carries the stamps: the conv with the most FLOPs among those whose kernel has them -- the fp32 MFMA
+    // kernel (fp32 plans; workgroup 0 of a ~0.8 ms launch) or the fused stem kernel (fp32 and bf16 plans)
+    int pick = -1;
+    double best = 0;
+    for (size_t i = 0; i < net->convs.size(); ++i) {
+        const ConvSlot &c = net->convs[i];
+        const bool stem = net->stem_fused && net->ops.size() > 1 && net->ops[1].kind == 0 && net->ops[1].index == (int)i;
+        if (!(stem || (net->dtype == Y3_DTYPE_F32 && !c.first_layer && !(net->stem_fused && i == (size_t)net->ops[0].index)))) continue;
+        const double ho = net->image_size ? net->image_size / c.d.out_div : 0;
+        const double fl = 2.0 * c.d.size * c.d.size * c.d.cin * c.d.cout * ho * ho;
+        if (fl > best) { best = fl; pick = (int)i; }
+    }
+    if (pick < 0) return fail(Y3_ERR_STATE, "y3_net_measure_sclk: no launch of this plan carries clock stamps (fp32 plan or fused stem needed)");
+    HIP_TRY(hipSetDevice(net->device));
+    unsigned long long *buf = nullptr, host[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), sizeof(host)));
+    // the chip's clock follows the load of the last milliseconds: stamp the stem kernel of the LAST of `forwards`
+    // back-to-back forwards, unstamped ones first
+    y3_status st = Y3_OK;
+    for (int i = 0; i < forwards && st == Y3_OK; ++i) {
+        net->clk_stamps = (i == forwards - 1) ? buf : nullptr;
+        net->clk_conv = (i == forwards - 1) ? pick : -1;
+        st = run(net, images_dev, batch, grids_dev, (hipStream_t)stream, nullptr, 0);
+    }
+    net->clk_stamps = nullptr;
+    net->clk_conv = -1;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (st != Y3_OK) return st;
+    if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_measure_sclk: %s", hipGetErrorString(e));
+    const double ticks = (double)(host[2] - host[0]), real = (double)(host[3] - host[1]);
+    if (!(real > 0.0) || !(ticks > 0.0)) return fail(Y3_ERR_STATE, "y3_net_measure_sclk: conv %d left no stamps", pick);
+    *mhz_out = (float)(ticks / real * 100.0);   // s_memrealtime counts at 100 MHz
+    return Y3_OK;
 }
 
 y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size_t *n_elems, void *stream)

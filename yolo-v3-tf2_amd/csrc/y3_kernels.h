@@ -36,6 +36,9 @@ struct ConvArgs {
     // fp32 classic schedule: 0 = every XCD takes a contiguous run of tiles (N fastest); gn in {1,2,4,8} = the XCDs form
     // an (8/gn) x gn grid over the (M-tile, N-tile) matrix (see conv_f32.hip)
     int xcd_gn;
+    // measurement only (y3_net_measure_sclk): when non-null, thread 0 of the middle workgroup stores {s_memtime, s_memrealtime}
+    // at its entry and after its epilogue -> the shader clock held while that workgroup ran.  Null in every product launch.
+    unsigned long long *clk_stamps;   // [4]
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to the
@@ -76,6 +79,10 @@ struct StemArgs {
     int leaky0, leaky1;
     unsigned img_bytes, dst_bytes;
     int tiles_y, tiles_x, n_tiles;   // filled by the launcher
+    // measurement only (y3_net_measure_sclk): when non-null, wave 0 of workgroup 0 stores {s_memtime, s_memrealtime} at
+    // kernel entry and exit -> shader clock held during the kernel = d(memtime) / d(memrealtime) x 100 MHz.  Null in
+    // every product launch: no stamp instruction executes then.
+    unsigned long long *clk_stamps;  // [4]
 };
 hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s);
 hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s);   // conv0 in fp32 arithmetic, bf16 patch, conv1 on bf16 MFMA

@@ -219,6 +219,16 @@ class Net:
 
     __call__ = forward
 
+    def measure_sclk(self, images: torch.Tensor, out: Sequence[torch.Tensor], forwards: int = 30) -> float:
+        """Shader clock (MHz) the chip holds under this network's load: `forwards` forwards back to back, the last one's
+        fused stem kernel stamps s_memtime / s_memrealtime (y3_net_measure_sclk).  Raises when the plan has no stem kernel."""
+        _need_cuda(images, *out)
+        ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in out])
+        mhz = C.c_float()
+        check(self.lib.y3_net_measure_sclk(self._h, _dev(images), images.shape[0], ptrs, int(forwards), C.byref(mhz),
+                                           _lib.stream_ptr()), "y3_net_measure_sclk")
+        return float(mhz.value)
+
     def read_tensor(self, tensor_id: int, batch: int) -> torch.Tensor:
         n = C.c_size_t()
         check(self.lib.y3_net_read_tensor(self._h, tensor_id, batch, None, C.byref(n), None), "y3_net_read_tensor")
