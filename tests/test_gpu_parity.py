@@ -1642,7 +1642,10 @@ def test_fused_stem_matches_oracle_and_the_two_launch_form(rt, S, B):
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
     from oracle import oracle as O
-    p = mini_program(3, [dict(filters=32, size=3), dict(filters=64, size=3, stride=2)],
+    # backbone.yaml layers 1-4: conv0, conv1, the 1x1 that follows (fp32 plans compute it inside the stem kernel too) and
+    # the 3x3 + shortcut that closes the first residual block; heads read the block's output
+    p = mini_program(3, [dict(filters=32, size=3), dict(filters=64, size=3, stride=2), dict(filters=32, size=1),
+                         dict(filters=64, size=3, shortcut=-3)],
                      [dict(filters=32, size=1), dict(filters=32, size=1), dict(filters=32, size=1)])
     w = synthetic_weights(p, seed=11)
     x = np.random.default_rng(11).random((B, S, S, 3), dtype=np.float32)
@@ -1658,6 +1661,7 @@ def test_fused_stem_matches_oracle_and_the_two_launch_form(rt, S, B):
         got = [g.clone() for g in net.forward(xd)]
         ms = net.profile_convs(xd)
         assert (ms[0] == 0.0) == fused, "fused stem did not engage" if fused else "fusion could not be switched off"
+        assert (ms[2] == 0.0) == fused, "the 1x1 third layer did not join the stem kernel"
         outs[fused] = got
         for r, g in zip(ref, got):
             g = g.cpu().numpy().reshape(r.shape)

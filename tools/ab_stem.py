@@ -45,7 +45,7 @@ def main():
             res[fused].append(ms)
             lay = net.profile_convs(x)
             print(f"round {r} fused={int(fused)} conv stack {ms:.3f} ms  {net.flops_per_image() * B / ms / 1e9:.1f} TF/s   "
-                  f"conv0 {lay[0]:.3f} ms conv1 {lay[1]:.3f} ms", flush=True)
+                  f"conv0 {lay[0]:.3f} conv1 {lay[1]:.3f} conv2 {lay[2]:.3f} ms", flush=True)
     for k, v in res.items():
         print(f"fused={int(k)}: min {min(v):.3f} ms  mean {sum(v) / len(v):.3f} ms")
 

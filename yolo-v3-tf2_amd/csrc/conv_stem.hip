@@ -13,6 +13,9 @@
 //   phase 2  conv1 as an implicit GEMM 128 pixels x 64 channels x K = 288 read ENTIRELY from LDS: A fragments from the
 //            patch, B fragments from the conv1 weights, which stay LDS-resident for the whole kernel.  No global load, no
 //            barrier and (all addresses = per-lane base + immediate) no vector ALU instruction inside the K loop.
+//   phase 3  (optional) the 1x1 conv that follows conv1 in the backbone (64 -> 32, reference backbone.yaml layer 3): conv1's
+//            tile is also written to LDS (the patch region, dead after phase 2) and contracted with the 1x1 weights held in
+//            registers on v_mfma_f32_16x16x4_f32 -- the 708 MB read of conv1's output by a separate launch disappears.
 // Recompute: 561 conv0 pixels per 512 consumed = 1.10 x the conv0 FLOPs (0.45 % of the network's).
 //
 // LDS (153,516 B of the CU's 160 KB; one workgroup per CU):
@@ -125,6 +128,35 @@ __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
     const int S = p.S, So = p.S >> 1;
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     const char *lds = reinterpret_cast<const char *>(smem);
+
+    // ---- phase 3 (1x1 conv on conv1's tile), wave-uniform switch ----
+    const bool with2 = p.w2 != nullptr;
+    // conv1 tile in LDS: [128 pixels][64 channels] fp32, 256 B per pixel, 16-B chunk c at c ^ (pixel & 15).
+    // Written from the phase-2 accumulators: pixel = 32 wm + m, m = (e & 3) + 8 (e >> 2) + 4 fh -> key (m & 15) =
+    // cm + 4 fh with cm = (e & 3) + 8 ((e >> 2) & 1); xt[j], j = (cm & 3) + 4 (cm >> 3): byte offset of channel n in such a pixel
+    int xt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cm = (j & 3) + 8 * (j >> 2);
+        xt[j] = ((((wn * 32 + fr) >> 2) ^ ((cm + 4 * fh) & 15)) << 4) + (fr & 3) * 4 + (wm * 32 + 4 * fh) * 256;
+    }
+    // read as A operand of v_mfma_f32_16x16x4_f32: lane (row = l & 15, q = l >> 4) of wave w holds pixel 16 w + row and, in
+    // step s, chunk 4 s + q = k 16 s + 4 q .. + 3 (MFMA j of the step contracts k = 16 s + 4 q + j over the four quarters)
+    const int l15 = lane & 15, lq = lane >> 4;
+    int a3[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a3[s] = (16 * wave + l15) * 256 + (((4 * s + lq) ^ l15) << 4);
+    f32x4 w2f[2][4];     // B fragments: channel n = l15 + 16 t, k = 16 s + 4 q .. + 3
+    float sh2[2] = {0.0f, 0.0f};
+    if (with2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w2f[t][s] = *reinterpret_cast<const f32x4 *>(p.w2 + (l15 + 16 * t) * C1 + 16 * s + 4 * lq);
+            sh2[t] = p.shift2[l15 + 16 * t];
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsd2 = __builtin_amdgcn_make_buffer_rsrc(with2 ? p.dst2 : p.dst, 0, with2 ? p.dst2_bytes : p.dst_bytes, 0x00020000);
 
     // image patch of a tile: element i of the 19 x 35 x 3 patch <- image (iy0 + i / 105, ix0 + (i % 105) / 3, channel);
     // positions outside the image read as 0 (conv0's 'same' padding) through the buffer range check
@@ -274,6 +306,41 @@ __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
                 if (p.leaky1) v = fmaxf(v, 0.1f * v);
                 const unsigned off = (unsigned)((((b * So + oy0 + rr) * So) + ox0 + cc) * C1 + n) * 4u;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, (int)off, 0, 0);
+                acc[e] = v;      // kept for phase 3
+            }
+        }
+        if (with2) {
+            __syncthreads();   // every wave is done reading the patch: it becomes conv1's tile
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int cm = (e & 3) + 8 * ((e >> 2) & 1);
+                const int imm = ((e & 3) + 8 * (e >> 2)) * 256;
+                *reinterpret_cast<float *>(const_cast<char *>(lds) + xt[(cm & 3) + 4 * (cm >> 3)] + imm) = acc[e];
+            }
+            __syncthreads();   // tile complete
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            f32x4v c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 fa = *reinterpret_cast<const f32x4 *>(lds + a3[s]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], w2f[0][s][j], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], w2f[1][s][j], c1, 0, 0, 0);
+                }
+            }
+            // C layout of 16x16: column = l & 15 (channel), rows 4 (l >> 4) + i (pixel 16 w + 4 q + i = tile row w, col 4 q + i)
+            const int oy = ty * TH + wave, ox = tx * TW + 4 * lq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v0 = c0[i] + sh2[0], v1 = c1[i] + sh2[1];
+                if (p.leaky2) {
+                    v0 = fmaxf(v0, 0.1f * v0);
+                    v1 = fmaxf(v1, 0.1f * v1);
+                }
+                const unsigned off = (unsigned)(((b * So + oy) * So + ox + i) * 32 + l15) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rsd2, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rsd2, (int)off, 64, 0);
             }
         }
         if (next < p.n_tiles) img_stage();

@@ -119,6 +119,7 @@ struct y3_net {
     int sk_cnt_cap = 0;
     int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 as one kernel when the graph allows it
     bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
+    bool stem_conv2 = false;       // ... and the 1x1 conv that follows them (64 -> 32) runs inside it as well (fp32 plans)
     unsigned long long *clk_stamps = nullptr;   // y3_net_measure_sclk: device buffer one conv launch stamps into (else null)
     int clk_conv = -1;                          // ... and which conv
     int xcd_mode = 1;              // y3_net_set_xcd_mode: 0 contiguous tile runs per XCD, 1 XCD-blocked order chosen per conv
@@ -349,6 +350,18 @@ static bool stem_applicable(const y3_net *net)
             if (x.src0 == a.dst || x.src1 == a.dst) return false;
         }
     }
+    return true;
+}
+
+// third op = 1x1 conv 64 -> 32 reading conv1's output (backbone.yaml layer 3): computed by the stem kernel from the tile it
+// still holds on chip (fp32 plans)
+static bool stem_conv2_applicable(const y3_net *net)
+{
+    if (net->dtype != Y3_DTYPE_F32 || net->ops.size() < 3 || net->ops[2].kind != 0) return false;
+    const y3_conv_desc &b = net->convs[net->ops[1].index].d, &c = net->convs[net->ops[2].index].d;
+    if (c.size != 1 || c.stride != 1 || c.cin != 64 || c.cout != 32 || c.residual >= 0 || c.src1 >= 0 || c.src0 != b.dst) return false;
+    for (int k = 0; k < 3; ++k)
+        if (net->outputs[k] == c.dst) return false;
     return true;
 }
 
@@ -667,7 +680,10 @@ y3_status y3_net_set_stem_fusion(y3_net *net, int on)
     if (!net || on < 0 || on > 1) return fail(Y3_ERR_INVALID, "y3_net_set_stem_fusion: argument must be 0 or 1");
     net->stem_mode = on;
     // takes effect at once on a planned net when the graph qualifies (decided again by the next y3_net_plan)
-    if (net->image_size) net->stem_fused = on && stem_applicable(net);
+    if (net->image_size) {
+        net->stem_fused = on && stem_applicable(net);
+        net->stem_conv2 = net->stem_fused && stem_conv2_applicable(net);
+    }
     return Y3_OK;
 }
 
@@ -831,6 +847,7 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
             }
     }
     net->stem_fused = net->stem_mode && stem_applicable(net);
+    net->stem_conv2 = net->stem_fused && stem_conv2_applicable(net);
     if (net->nclasses > 0) {   // scratch of y3_net_detect: no allocation inside the stream-ordered call
         size_t off[9], n_boxes, gelems[3];
         int32_t gs[3];
@@ -962,7 +979,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.xcd_gn = 0;
             a.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : nullptr;   // fp32 MFMA kernel and stem only
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
-            if (net->stem_fused && oi == 0) {       // conv0 runs inside conv1's launch (fused stem)
+            if ((net->stem_fused && oi == 0) || (net->stem_conv2 && oi == 2)) {   // runs inside conv1's launch (fused stem)
                 if (ms_out && o.index < n_ms) ms_out[o.index] = 0.0f;
                 continue;
             }
@@ -986,6 +1003,15 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 sa.img_bytes = (unsigned)bytes(c0.d.src0);
                 sa.dst_bytes = a.dst_bytes;
                 sa.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : nullptr;
+                if (net->stem_conv2) {
+                    const ConvSlot &c2 = net->convs[net->ops[2].index];
+                    sa.w2 = c2.w_dev;
+                    sa.shift2 = c2.shift_dev;
+                    sa.dst2 = ptr(c2.d.dst);
+                    sa.leaky2 = c2.d.leaky;
+                    sa.dst2_bytes = (unsigned)bytes(c2.d.dst);
+                    if (!sa.dst2) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", net->ops[2].index);
+                }
                 e = bf ? y3::launch_conv_stem_bf16(sa, s) : y3::launch_conv_stem_f32(sa, s);
             } else if ((bf || x3 || x2) && c.first_layer) {
                 if (is_out(d.dst)) return fail(Y3_ERR_INVALID, "conv %d: first layer cannot be a head in this mode", o.index);
