@@ -246,55 +246,65 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
     // ---- epilogue through LDS, one 32-row sub-tile of every wave per pass ----------------------------------
     // pass i: wave (wr, wc) writes rows [wr*32, +32) x cols [wc*32*TN, +32*TN) of a [WR*32][BN+4] fp32 tile (its i-th
     // accumulator row block), then all threads convert 8 consecutive channels each and store 16 B.
-    constexpr int EROWS = WR * 32;
-    constexpr int PPR = BN / 8;                       // 16-byte pieces (8 bf16) per row
-    constexpr int NPC = (EROWS * PPR + NT - 1) / NT;  // pieces per thread per pass
-    float *C = reinterpret_cast<float *>(smem);
-    unsigned short *dstb = static_cast<unsigned short *>(p.dst);
-    const unsigned short *res = static_cast<const unsigned short *>(p.residual);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        // tile row of chunk row r: (r / 32) * 32 * TM + i * 32 + r % 32
-        u32x4 rr[OUT_F32 ? 1 : NPC];
-        if (!OUT_F32 && res) {   // shortcut operand first: its latency hides behind the accumulator write-out
-#pragma unroll
-            for (int it = 0; it < NPC; ++it) {
-                const int pc = tid + it * NT;
-                const int r = pc / PPR, ch = (pc - r * PPR) * 8;
-                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31);
-                rr[it] = (pc < EROWS * PPR && m < p.M) ? *reinterpret_cast<const u32x4 *>(res + (size_t)m * p.Cout + n0 + ch)
-                                                       : u32x4{0u, 0u, 0u, 0u};
-            }
-        }
-        if (i > 0) __syncthreads();   // previous pass fully read
+#ifdef Y3_AB_PROBE_NO_EPILOGUE
+    // timing-only A/B build (tools/ab_libs.py): what does the epilogue cost?  The condition is always true at run time, but
+    // opaque to the compiler: the epilogue stays in the binary (same registers, same code layout) and never runs.
+    if (p.leaky >= 0) return;
+#endif
+    if constexpr (!OUT_F32) {
+        // ---- bf16 output: per-wave epilogue, no workgroup barrier ------------------------------------------------------
+        // Every wave transposes its own 32 x (32 TN) fp32 blocks through a private LDS scratch (the operand tiles are dead
+        // after the loop's last barrier) and stores whole 16-byte pieces of 8 channels: rows of 64 TN bytes per wave, full
+        // 128-B lines for TN >= 2.  LDS operations of one wave execute in order, so the write -> read hand-off between
+        // its lanes needs no barrier, and a wave leaves as soon as ITS stores are issued.  The shortcut operand is added
+        // in fp32 before the single rounding to bf16 (the oracle's bf16 mode rounds where the pipeline stores).
+        // (round 3: the workgroup-wide fp32 tile + 2 barriers per pass this replaces cost 27 % of the bf16 conv stack,
+        // profiles/r03_ab_bf16_epilogue_probe.txt)
+        constexpr int CW = 32 * TN;              // floats per scratch row = channels per wave
+        constexpr int PPRW = CW / 8;             // 16-byte output pieces per row
+        constexpr int NPL = 32 * PPRW / 64;      // pieces per lane per 32-row block
+        float *S = reinterpret_cast<float *>(smem) + wave * (32 * CW);
+        unsigned short *dstb = static_cast<unsigned short *>(p.dst);
+        const unsigned short *res = static_cast<const unsigned short *>(p.residual);
+        const int nw = n0 + wc * CW;             // first channel of this wave
+        float sc[TN], sh[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int nl = (wc * TN + j) * 32 + fr;
-            const float sc = p.scale[n0 + nl], sh = p.shift[n0 + nl];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] * sc + sh;
-                if (p.leaky) v = fmaxf(v, 0.1f * v);
-                C[(wr * 32 + 4 * fh + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
-            }
+            sc[j] = p.scale[nw + j * 32 + fr];
+            sh[j] = p.shift[nw + j * 32 + fr];
         }
-        __syncthreads();
-        if (OUT_F32) {
-            float *dst = static_cast<float *>(p.dst);
-            for (int idx = tid; idx < EROWS * BN; idx += NT) {
-                const int r = idx / BN, col = idx - r * BN;
-                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31), n = n0 + col;
-                if (m < p.M && n < p.Cout) dst[(size_t)m * p.Cout + n] = C[r * CROW + col];
-            }
-        } else {
 #pragma unroll
-            for (int it = 0; it < NPC; ++it) {
-                const int pc = tid + it * NT;
-                const int r = pc / PPR, ch = (pc - r * PPR) * 8;
-                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31);
-                if (pc >= EROWS * PPR || m >= p.M) continue;
-                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(C + r * CROW + ch);
-                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(C + r * CROW + ch + 4);
+        for (int i = 0; i < TM; ++i) {
+            const int mw = m0 + (wr * TM + i) * 32;   // first row of this block
+            u32x4 rr[NPL];
+#ifdef Y3_AB_PROBE_NO_RESLOAD
+            if (res && p.leaky < 0) {   // timing-only A/B build: the shortcut loads never execute
+#else
+            if (res) {   // shortcut operand first: its latency hides behind the accumulator write-out
+#endif
+#pragma unroll
+                for (int it = 0; it < NPL; ++it) {
+                    const int q = lane + it * 64;
+                    const int r = q / PPRW, pc = q - r * PPRW;
+                    rr[it] = (mw + r < p.M) ? *reinterpret_cast<const u32x4 *>(res + (size_t)(mw + r) * p.Cout + nw + pc * 8)
+                                            : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][j][e] * sc[j] + sh[j];
+                    if (p.leaky) v = fmaxf(v, 0.1f * v);
+                    S[(4 * fh + (e & 3) + 8 * (e >> 2)) * CW + j * 32 + fr] = v;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NPL; ++it) {
+                const int q = lane + it * 64;
+                const int r = q / PPRW, pc = q - r * PPRW;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(S + r * CW + pc * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(S + r * CW + pc * 8 + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if (res) {
 #pragma unroll
@@ -306,12 +316,53 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
                 u32x4 out;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) out[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
-                *reinterpret_cast<u32x4 *>(dstb + (size_t)m * p.Cout + n0 + ch) = out;
+#ifdef Y3_AB_PROBE_NO_STORE
+                if (p.leaky < 0)   // timing-only A/B build: never true at run time (opaque to the compiler): no output store executes
+#endif
+                if (mw + r < p.M) *reinterpret_cast<u32x4 *>(dstb + (size_t)(mw + r) * p.Cout + nw + pc * 8) = out;
+            }
+        }
+    } else {
+        // ---- fp32 output (head grids, Cout = 255): workgroup-wide fp32 tile, one 32-row block of every wave per pass ----
+        constexpr int EROWS = WR * 32;
+        float *C = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (i > 0) __syncthreads();   // previous pass fully read
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = (wc * TN + j) * 32 + fr;
+                const float sc = p.scale[n0 + nl], sh = p.shift[n0 + nl];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][j][e] * sc + sh;
+                    if (p.leaky) v = fmaxf(v, 0.1f * v);
+                    C[(wr * 32 + 4 * fh + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
+                }
+            }
+            __syncthreads();
+            float *dst = static_cast<float *>(p.dst);
+            for (int idx = tid; idx < EROWS * BN; idx += NT) {
+                const int r = idx / BN, col = idx - r * BN;
+                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31), n = n0 + col;
+                if (m < p.M && n < p.Cout) dst[(size_t)m * p.Cout + n] = C[r * CROW + col];
             }
         }
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round-3 record (code removed again): a PERSISTENT form of this kernel -- workgroups walking tiles bid, bid + G, ...,
+// the next tile's first K tile prefetched before the epilogue, a counted s_waitcnt leaving the tile's stores in flight --
+// was built to hide the output stores (profiles/r03_ab_bf16_epilogue_probe.txt: the stores alone cost 20 % of the bf16
+// conv stack: 10.0 ms with them, 8.0 without).  Bit-identical, 34 bf16 parity tests green, and 10 % SLOWER (11.09 vs
+// 10.07 ms, profiles/r03_ab_bf16_persistent.txt).  Two facts defeat it: (1) memory operations retire in issue order, so the
+// first wait for a K tile issued after the stores waits for the stores as well -- they can overlap one K iteration
+// (~1 us), not a tile; (2) with one workgroup per CU (128 KB of LDS) and equal work per tile all 256 workgroups store at
+// the same moment: a 32 MB burst, 4 MB per XCD = the whole L2, which drains at the HBM write rate (~8 us) while HBM idles
+// during the K loops.  What would help is out-of-phase workgroups (two per CU), which this tile's LDS and register
+// budget do not admit.
+// ---------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------
 // Pipelined 256x256x64 tile (tile id 20): the K loop of cdna_hip_programming.md section 5 "256^2 8-phase template",
 // adapted to the implicit-GEMM gather.  8 waves (2 along M x 4 along N), 128x64 per wave, 128 KB of LDS = two K-tile
@@ -596,7 +647,8 @@ static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
     const size_t stages = 2 * (size_t)(BM + BN) * (DMA ? 2 * BK : 2 * BK + 16);
-    const size_t ctile = (size_t)WR * 32 * (BN + 4) * sizeof(float);   // epilogue tile: one 32-row block per wave row
+    // epilogue: fp32 output -> one workgroup-wide 32-row block per wave row; bf16 output -> 32 x (32 TN) floats per wave
+    const size_t ctile = OUT_F32 ? (size_t)WR * 32 * (BN + 4) * sizeof(float) : (size_t)WR * WC * 32 * 32 * TN * sizeof(float);
     const size_t lds = stages > ctile ? stages : ctile;
     auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, DMA>;
     static LdsAttrOnce attr;  // per instantiation

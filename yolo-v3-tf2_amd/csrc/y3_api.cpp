@@ -1193,6 +1193,8 @@ y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, f
     // the chip's clock follows the load of the last milliseconds: stamp the stem kernel of the LAST of `forwards`
     // back-to-back forwards, unstamped ones first
     y3_status st = Y3_OK;
+    const int lanes_saved = net->lanes;
+    net->lanes = 1;             // one launch of the stamped conv (concurrent sub-batches would each stamp the same words)
     for (int i = 0; i < forwards && st == Y3_OK; ++i) {
         net->clk_stamps = (i == forwards - 1) ? buf : nullptr;
         net->clk_conv = (i == forwards - 1) ? pick : -1;
@@ -1200,6 +1202,7 @@ y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, f
     }
     net->clk_stamps = nullptr;
     net->clk_conv = -1;
+    net->lanes = lanes_saved;
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e == hipSuccess) e = hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost);
     (void)hipFree(buf);
