@@ -403,7 +403,9 @@ def main():
                        "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
                        "mean_num_valid": round(nv_mean, 2)},
             "roofline": {
-                "bound": "mfma", "kernel": f"conv stack (74 x conv_{'f32x3' if args.dtype == 'f32x2' else args.dtype}_mfma{'<2 planes>' if args.dtype == 'f32x2' else ''} launches + 1 first-layer conv per step)",
+                "bound": "mfma", "kernel": ("conv stack (fused stem kernel = conv0..2 in one launch + 72 x conv_f32_mfma launches per step)" if args.dtype == "f32"
+                                            else "conv stack (fused stem kernel = conv0..1 in one launch + 73 x conv_bf16_mfma launches per step)" if args.dtype == "bf16"
+                                            else f"conv stack (74 x conv_f32x3_mfma{'<2 planes>' if args.dtype == 'f32x2' else ''} launches + 1 first-layer conv per step)"),
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved * mfma_flops_factor / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None, "sclk_source": sclk_src,
@@ -424,14 +426,17 @@ def main():
         if args.per_layer:
             net.plan(B, S, dt_ids[args.dtype])       # the alt measurements re-planned the net: back to the headline mode
             ms = net.profile_convs(images)
+            fused_fl = sum(2.0 * o.size * o.size * o.cin * o.cout * (S // o.out_div) ** 2 * B
+                           for o, t in zip(net.conv_ops, ms) if t <= 0)
+            carrier = next((o.conv_index for o, t in zip(net.conv_ops, ms) if t > 0), -1) if fused_fl else -1
             for o, t in zip(net.conv_ops, ms):
-                if t <= 0:      # conv0 of the fused stem: its work is inside conv1's launch
-                    print(f"conv{o.conv_index:<3d} {o.size}x{o.size}/{o.stride} {o.cin:>4d}->{o.cout:<4d}  (fused into the next launch)", file=sys.stderr)
+                if t <= 0:      # conv0 / the 1x1 third layer of the fused stem: their work is inside conv1's launch
+                    print(f"conv{o.conv_index:<3d} {o.size}x{o.size}/{o.stride} {o.cin:>4d}->{o.cout:<4d}  (inside the fused stem launch, timed with conv{carrier})", file=sys.stderr)
                     continue
                 ho = S // o.out_div
-                fl = 2.0 * o.size * o.size * o.cin * o.cout * ho * ho * B
+                fl = 2.0 * o.size * o.size * o.cin * o.cout * ho * ho * B + (fused_fl if o.conv_index == carrier else 0.0)
                 print(f"conv{o.conv_index:<3d} {o.size}x{o.size}/{o.stride} {o.cin:>4d}->{o.cout:<4d} @{ho:<3d} "
-                      f"{t:8.3f} ms {fl / t / 1e9:8.1f} TF/s", file=sys.stderr)
+                      f"{t:8.3f} ms {fl / t / 1e9:8.1f} TF/s" + ("  (fused stem: incl. the layers timed with it)" if o.conv_index == carrier else ""), file=sys.stderr)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
