@@ -131,6 +131,11 @@ y3_status y3_net_set_sk_grid(y3_net *net, int workgroups);
  * its L2 (the 256->512 / 512->1024 3x3 weights are 4.7 / 18.9 MB); 0: every XCD takes a contiguous run of tiles.
  * Results are bit-identical in both modes (same per-tile arithmetic). */
 y3_status y3_net_set_xcd_mode(y3_net *net, int mode);
+/* K order of the fp32 3x3 convs.  channels > 0 (a multiple of 32): for every chunk of that many input channels all 9 taps,
+ * then the next chunk, so that the 9 reads of a pixel (one per tap) fall close together in time and hit in L2 (the tap-
+ * major order re-fetched the operands of the 13x13 layers ~18x from beyond L2).  The same products in another summation
+ * order: results differ from the tap-major ones in the last bits.  0: tap-major; -1 (default): chosen per conv. */
+y3_status y3_net_set_k_chunk(y3_net *net, int channels);
 y3_status y3_net_keep_activations(y3_net *net, int keep);
 /* 1 (default): when the program starts with conv0 (3x3/1, 3 -> 32) feeding only conv1 (3x3/2, 32 -> 64) -- the Darknet-53
  * stem, reference config/models/yolov3/backbone.yaml layers 1-2 -- and the plan is fp32 without keep_activations, the two
@@ -145,6 +150,17 @@ y3_status y3_net_set_stem_fusion(y3_net *net, int on);
  * stream.  No product launch carries stamps (the kernels test a null pointer). */
 y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
                               float *mhz_out, void *stream);
+/* The same measurement on the launch of conv slot `conv` (tools/sclk_per_layer.py: the clock differs from layer to layer
+ * with the power each one draws).  Y3_ERR_STATE when that conv's kernel carries no stamps in this plan. */
+y3_status y3_net_measure_sclk_conv(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
+                                   int conv, float *mhz_out, void *stream);
+/* ... and on every conv launch of ONE forward (the last of `forwards`): mhz_out[n_convs] (0 where the conv's kernel
+ * carries no stamps or runs inside another launch), and -- when not NULL -- start_us / end_us [n_convs]: when the
+ * first workgroup of each launch began and when its clock-stamped (middle) workgroup ended on the chip's 100 MHz
+ * real-time counter, relative to the earliest stamp: the timeline of the conv stack with no host event in it; the
+ * difference of consecutive starts is a launch's duration in the real forward (bench.py: time-weighted clock). */
+y3_status y3_net_measure_sclk_all(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
+                                  float *mhz_out, double *start_us, double *end_us, void *stream);
 /* Before y3_net_plan: run the first n_convs convs chunk_images images at a time, then the rest of the network on the
  * whole batch.  The first layers' activations are the largest tensors of the network (1.4 GB for 64 images at 416x416);
  * in chunks they are still in the Infinity Cache when the next conv reads them.  Results are unchanged (images are

@@ -25,7 +25,7 @@ CANDIDATES = {
     "f32": [3, 4, 5, 6, 9, 10, 11, 12, 17, 18, 23, 26, 27, 29, 31, 32, 33, 34, 37, 38, 39, 40],   # 33..40: stream-K schedule
     "f32x2": [0, 1, 2, 3, 4, 8, 12, 26, 27],
     "f32x3": [0, 1, 2, 3, 4, 5, 8, 12, 26, 27],
-    "bf16": [0, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19],
+    "bf16": [0, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 28, 29],
 }
 
 
@@ -81,8 +81,13 @@ def main():
 
     best = measure()
     print(f"start: {best:.3f} ms  ({B / best * 1e3:.0f} img/s)", flush=True)
+    # The chip warms up over the run (round 3: 10.07 -> 10.17 ms with nothing changed), so a candidate is compared with
+    # the CURRENT tile measured right before it, and a winner must win a second, re-measured pair.
     for sig in sorted(sigs, key=lambda s: -sigs[s]["flops"]):
         cur = int(table.get(sig, -1))
+        apply(sig, cur)
+        ref = measure()
+        cand = {}
         for t in CANDIDATES[a.dtype]:
             if t == cur:
                 continue
@@ -90,13 +95,23 @@ def main():
                 apply(sig, t)
             except runtime.Y3Error:
                 continue                             # tile does not fit this conv
-            ms = measure()
-            if ms < best * (1.0 - a.min_gain):
-                print(f"  {sig}: tile {cur} -> {t}: {best:.3f} -> {ms:.3f} ms", flush=True)
-                best, cur = ms, t
+            cand[t] = measure()
+        apply(sig, cur)
+        ref = min(ref, measure())
+        if cand:
+            t = min(cand, key=cand.get)
+            if cand[t] < ref * (1.0 - a.min_gain):
+                apply(sig, t)
+                again = measure()
+                apply(sig, cur)
+                ref2 = measure()
+                if again < ref2 * (1.0 - a.min_gain):
+                    print(f"  {sig}: tile {cur} -> {t}: {ref2:.3f} -> {again:.3f} ms", flush=True)
+                    cur = t
         apply(sig, cur)
         table[sig] = cur
-        print(f"  {sig}: keeps tile {cur} ({best:.3f} ms)", flush=True)   # progress line (a silent run looks hung)
+        print(f"  {sig}: keeps tile {cur} (ref {ref:.3f} ms; best other "
+              f"{min(cand.values()) if cand else float('nan'):.3f} ms)", flush=True)   # progress line
     final = measure()
     print(f"final: {final:.3f} ms  ({B / final * 1e3:.0f} img/s)", flush=True)
     if a.write:

@@ -61,7 +61,10 @@ TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4
               (128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (64, 128, 4, 64), (128, 256, 8, 64),  # 8..13: LDS-DMA loads
               (256, 256, 8, 64), (256, 128, 4, 64), (128, 256, 4, 64),  # 14..16: LDS-DMA, bigger wave tiles
               (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64),  # 17..19: LDS-DMA, 16 waves
-              (256, 256, 8, 64)]  # 20: pipelined K loop (prefetch in flight across raw barriers, counted vmcnt)
+              (256, 256, 8, 64),  # 20: pipelined K loop (prefetch in flight across raw barriers, counted vmcnt)
+              (128, 256, 8, 32), (256, 128, 8, 32), (128, 128, 4, 32),  # 21..23: LDS-DMA, BK 32: several workgroups per CU
+              (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64),  # 24..26: tiles 17..19 on 16x16x32 MFMAs
+              (128, 128, 4, 64), (128, 64, 4, 64), (64, 128, 4, 64)]       # 27..29: tiles 8, 10, 12 on 16x16x32 MFMAs
 TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if (26 <= i <= 32 or 37 <= i <= 40 or i in (42, 43, 45)) else "")
               + ("sk" if 33 <= i <= 40 else "") + ("rp" if i >= 41 else "")
               for i, (bm, bn, w, st) in enumerate(TILES)]
@@ -108,8 +111,11 @@ SYMBOLS = {
     "y3_net_set_lanes": (_i, [_vp, _i]),
     "y3_net_set_sk_grid": (_i, [_vp, _i]),
     "y3_net_set_xcd_mode": (_i, [_vp, _i]),
+    "y3_net_set_k_chunk": (_i, [_vp, _i]),
     "y3_net_set_stem_fusion": (_i, [_vp, _i]),
     "y3_net_measure_sclk": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _fp, _vp]),
+    "y3_net_measure_sclk_conv": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _i, _fp, _vp]),
+    "y3_net_measure_sclk_all": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _fp, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),
     "y3_net_plan": (_i, [_vp, _i, _i, _i]),
     "y3_net_forward": (_i, [_vp, _vp, _i, C.POINTER(_vp), _vp]),
     "y3_net_read_tensor": (_i, [_vp, _i, _i, _vp, C.POINTER(_sz), _vp]),

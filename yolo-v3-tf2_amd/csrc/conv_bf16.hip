@@ -33,10 +33,21 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 
 // DMA: operand tiles filled by direct-to-LDS buffer loads (BK = 64 only): unpadded 128-B rows, 16-B chunk index
 // XOR-swizzled with (row >> 1) & 7 on the source address and on the fragment reads (see conv_f32.hip).
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false>
-__global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
+// DMA with BK = 32 (round 3): 64-B rows, a wave instruction fills 16 rows, chunk index XOR-ed with (row >> 2) & 3.  Half the
+// LDS per stage: 128x256 / 256x128 tiles of 8 waves fit TWO workgroups per CU (MINW = 4 caps the registers at 128), so that
+// one workgroup's epilogue (27 % of the bf16 conv stack, profiles/r03_ab_bf16_epilogue_probe.txt) runs beside the other's K loop.
+// M16 (round 3): the same tile on v_mfma_f32_16x16x32_bf16 -- 2TM x 2TN blocks of 16x16 per wave instead of TM x TN of 32x32.
+// Same LDS image, same bytes read per K tile, same MFMA cycles per FLOP; the chip holds a higher clock on this shape
+// (MI355X_MICROARCH.md "DVFS give-back" item 7: 1.12-1.15 x the FLOP/s on random data).  Fragment: lane l holds k = 8 (l >> 4) ..
+// + 7 of row l & 15; C: acc[mb][nb][j] = row 16 mb + 4 (l >> 4) + j, column 16 nb + (l & 15).
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false, int MINW = 1, bool M16 = false>
+__global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvArgs p)
 {
-    static_assert(!DMA || BK == 64, "LDS-DMA variant needs 128-byte rows");
+    static_assert(!DMA || BK == 64 || BK == 32, "LDS-DMA variant needs 128-byte or 64-byte rows");
+    static_assert(!M16 || (DMA && BK == 64), "the 16x16x32 form is built on the 128-byte swizzled rows");
+    constexpr int MB = M16 ? 2 * TM : TM, NB = M16 ? 2 * TN : TN;   // accumulator blocks per wave
+    using acc_t = typename std::conditional<M16, f32x4, f32x16>::type;
+    constexpr int DROWS = 1024 / (2 * BK);   // rows one wave DMA instruction (1 KiB) fills: 8 (BK 64) or 16 (BK 32)
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
     constexpr int NT = 64 * WR * WC;
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
     const int lrow = tid / LPR;
     // first bf16 of this lane's 16-B piece inside the K tile (DMA: physical chunk tid & 7 holds logical chunk
     // (tid & 7) ^ ((row >> 1) & 7))
-    const int lchunk = DMA ? (((tid % LPR) ^ ((lrow >> 1) & 7)) * 8) : (tid % LPR) * 8;
+    const int lchunk = DMA ? (BK == 64 ? (((tid % LPR) ^ ((lrow >> 1) & 7)) * 8) : (((tid % LPR) ^ ((lrow >> 2) & 3)) * 8)) : (tid % LPR) * 8;
     int aoff[AP];
     int aoff1[CONCAT ? AP : 1];
     int ahw[AP];
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
     int kglob = 0;
     typedef __attribute__((address_space(3))) void *lds_ptr;
     auto fetch_dma = [&](int buf) {
-        unsigned char *sa = smem + buf * STAGE_B + wave * 8 * ROWB;   // wave w fills rows [pass*RP + 8w, +8)
+        unsigned char *sa = smem + buf * STAGE_B + wave * DROWS * ROWB;   // wave w fills rows [pass*RP + DROWS*w, +DROWS)
         unsigned char *sb = sa + BM * ROWB;
         if (CONCAT && c0 >= p.C0) {
 #pragma unroll
@@ -190,13 +201,13 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
         for (int j = 0; j < BP; ++j) *reinterpret_cast<u32x4 *>(sb + (j * RP + lrow) * ROWB + lchunk * 2) = rb[j];
     };
 
-    f32x16 acc[TM][TN];
+    acc_t acc[MB][NB];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int e = 0; e < (M16 ? 4 : 16); ++e) acc[i][j][e] = 0.0f;
 
     const int KT = p.K / BK;
     if (DMA) {
@@ -208,12 +219,16 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
     }
     __syncthreads();
 
-    const int fr = lane & 31, fh = lane >> 5;
+    const int fr = M16 ? (lane & 15) : (lane & 31), fh = M16 ? (lane >> 4) : (lane >> 5);   // row in the block, k group
     const int a_frag = (wr * 32 * TM + fr) * ROWB + (DMA ? 0 : fh * 16);
     const int b_frag = BM * ROWB + (wc * 32 * TN + fr) * ROWB + (DMA ? 0 : fh * 16);
-    int foff[BK / 16];  // byte offset of this lane's 16-B piece of k-step s inside its row
+    constexpr int KS = M16 ? BK / 32 : BK / 16;      // MFMA k steps per K tile
+    constexpr int BR = M16 ? 16 : 32;                // rows per block
+    int foff[KS];  // byte offset of this lane's 16-B piece of k-step s inside its row
 #pragma unroll
-    for (int s_ = 0; s_ < BK / 16; ++s_) foff[s_] = DMA ? (((2 * s_ + fh) ^ ((fr >> 1) & 7)) * 16) : s_ * 32;
+    for (int s_ = 0; s_ < KS; ++s_)
+        foff[s_] = M16 ? (((4 * s_ + fh) ^ ((fr >> 1) & 7)) * 16)
+                       : DMA ? (BK == 64 ? (((2 * s_ + fh) ^ ((fr >> 1) & 7)) * 16) : (((2 * s_ + fh) ^ ((fr >> 2) & 3)) * 16)) : s_ * 32;
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
@@ -223,17 +238,19 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
         const unsigned char *sa = smem + cur * STAGE_B + a_frag;
         const unsigned char *sb = smem + cur * STAGE_B + b_frag;
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 fa[TM], fb[TN];
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 fa[MB], fb[NB];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(sa + i * 32 * ROWB + foff[s]);
+            for (int i = 0; i < MB; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(sa + i * BR * ROWB + foff[s]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(sb + j * 32 * ROWB + foff[s]);
+            for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(sb + j * BR * ROWB + foff[s]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < MB; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NB; ++j) {
+                    if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
         }
         if (DMA) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -267,11 +284,11 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
         unsigned short *dstb = static_cast<unsigned short *>(p.dst);
         const unsigned short *res = static_cast<const unsigned short *>(p.residual);
         const int nw = n0 + wc * CW;             // first channel of this wave
-        float sc[TN], sh[TN];
+        float sc[NB], sh[NB];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            sc[j] = p.scale[nw + j * 32 + fr];
-            sh[j] = p.shift[nw + j * 32 + fr];
+        for (int j = 0; j < NB; ++j) {
+            sc[j] = p.scale[nw + j * BR + fr];
+            sh[j] = p.shift[nw + j * BR + fr];
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -290,13 +307,26 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
                                             : u32x4{0u, 0u, 0u, 0u};
                 }
             }
+            if constexpr (M16) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+                for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = acc[i][j][e] * sc[j] + sh[j];
-                    if (p.leaky) v = fmaxf(v, 0.1f * v);
-                    S[(4 * fh + (e & 3) + 8 * (e >> 2)) * CW + j * 32 + fr] = v;
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[2 * i + mb][j][e] * sc[j] + sh[j];
+                            if (p.leaky) v = fmaxf(v, 0.1f * v);
+                            S[(16 * mb + 4 * fh + e) * CW + j * 16 + fr] = v;
+                        }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[i][j][e] * sc[j] + sh[j];
+                        if (p.leaky) v = fmaxf(v, 0.1f * v);
+                        S[(4 * fh + (e & 3) + 8 * (e >> 2)) * CW + j * 32 + fr] = v;
+                    }
                 }
             }
 #pragma unroll
@@ -330,14 +360,25 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_bf16_mfma(const ConvArgs p)
         for (int i = 0; i < TM; ++i) {
             if (i > 0) __syncthreads();   // previous pass fully read
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = (wc * TN + j) * 32 + fr;
+            for (int j = 0; j < NB; ++j) {
+                const int nl = wc * TN * 32 + j * BR + fr;
                 const float sc = p.scale[n0 + nl], sh = p.shift[n0 + nl];
+                if constexpr (M16) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = acc[i][j][e] * sc + sh;
-                    if (p.leaky) v = fmaxf(v, 0.1f * v);
-                    C[(wr * 32 + 4 * fh + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[2 * i + mb][j][e] * sc + sh;
+                            if (p.leaky) v = fmaxf(v, 0.1f * v);
+                            C[(wr * 32 + 16 * mb + 4 * fh + e) * CROW + nl] = v;
+                        }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[i][j][e] * sc + sh;
+                        if (p.leaky) v = fmaxf(v, 0.1f * v);
+                        C[(wr * 32 + 4 * fh + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
+                    }
                 }
             }
             __syncthreads();
@@ -627,6 +668,8 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {256, 256, 8, 64}, {256, 128, 4, 64}, {128, 256, 4, 64},  // 14..16: LDS-DMA, 128x64 / 64x128 wave tiles
     {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64},   // 17..19: LDS-DMA, 16 waves (64x64 / 64x32 / 32x64 wave tiles)
     {256, 256, 8, 64},                                            // 20: pipelined K loop (counted vmcnt, raw barriers)
+    {128, 256, 8, 32}, {256, 128, 8, 32}, {128, 128, 4, 32},      // 21..23: LDS-DMA with BK = 32, several workgroups per CU
+    {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64}, {128, 128, 4, 64}, {128, 64, 4, 64}, {64, 128, 4, 64},  // 24..29: 16x16x32 MFMAs
 };
 
 TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < BF16_TILE_COUNT) ? tile : 0]; }
@@ -641,7 +684,7 @@ bool conv_bf16_tile_built(int tile)
 #endif
 }
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false>
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false, int MINW = 1, bool M16 = false>
 static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
@@ -650,19 +693,19 @@ static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
     // epilogue: fp32 output -> one workgroup-wide 32-row block per wave row; bf16 output -> 32 x (32 TN) floats per wave
     const size_t ctile = OUT_F32 ? (size_t)WR * 32 * (BN + 4) * sizeof(float) : (size_t)WR * WC * 32 * 32 * TN * sizeof(float);
     const size_t lds = stages > ctile ? stages : ctile;
-    auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, DMA>;
+    auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, DMA, MINW, M16>;
     static LdsAttrOnce attr;  // per instantiation
     if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }
 
-template <int TM, int TN, int WR, int WC, int BK, bool DMA = false>
+template <int TM, int TN, int WR, int WC, int BK, bool DMA = false, int MINW = 1, bool M16 = false>
 static hipError_t launch_tb(const ConvArgs &a, bool out_f32, hipStream_t s)
 {
     if (a.src1)
-        return out_f32 ? launch_kb<TM, TN, WR, WC, BK, true, true, DMA>(a, s) : launch_kb<TM, TN, WR, WC, BK, true, false, DMA>(a, s);
-    return out_f32 ? launch_kb<TM, TN, WR, WC, BK, false, true, DMA>(a, s) : launch_kb<TM, TN, WR, WC, BK, false, false, DMA>(a, s);
+        return out_f32 ? launch_kb<TM, TN, WR, WC, BK, true, true, DMA, MINW, M16>(a, s) : launch_kb<TM, TN, WR, WC, BK, true, false, DMA, MINW, M16>(a, s);
+    return out_f32 ? launch_kb<TM, TN, WR, WC, BK, false, true, DMA, MINW, M16>(a, s) : launch_kb<TM, TN, WR, WC, BK, false, false, DMA, MINW, M16>(a, s);
 }
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
@@ -700,6 +743,15 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
         case 17: return launch_tb<2, 2, 4, 4, 64, true>(a, out_f32, s);   // 256x256, 16 waves, LDS-DMA
         case 18: return launch_tb<2, 1, 4, 4, 64, true>(a, out_f32, s);   // 256x128, 16 waves, LDS-DMA
         case 19: return launch_tb<1, 2, 4, 4, 64, true>(a, out_f32, s);   // 128x256, 16 waves, LDS-DMA
+        case 21: return launch_tb<2, 2, 2, 4, 32, true, 4>(a, out_f32, s);   // 128x256, 8 waves, BK 32, two workgroups per CU
+        case 22: return launch_tb<2, 2, 4, 2, 32, true, 4>(a, out_f32, s);   // 256x128, 8 waves, BK 32, two workgroups per CU
+        case 23: return launch_tb<2, 2, 2, 2, 32, true, 4>(a, out_f32, s);   // 128x128, 4 waves, BK 32: up to four workgroups per CU
+        case 24: return launch_tb<2, 2, 4, 4, 64, true, 1, true>(a, out_f32, s);   // tile 17 on 16x16x32 MFMAs
+        case 25: return launch_tb<2, 1, 4, 4, 64, true, 1, true>(a, out_f32, s);   // tile 18 on 16x16x32
+        case 26: return launch_tb<1, 2, 4, 4, 64, true, 1, true>(a, out_f32, s);   // tile 19 on 16x16x32
+        case 27: return launch_tb<2, 2, 2, 2, 64, true, 1, true>(a, out_f32, s);   // tile 8 (128x128, 4 waves) on 16x16x32
+        case 28: return launch_tb<2, 1, 2, 2, 64, true, 1, true>(a, out_f32, s);   // tile 10 (128x64, 4 waves) on 16x16x32
+        case 29: return launch_tb<1, 2, 2, 2, 64, true, 1, true>(a, out_f32, s);   // tile 12 (64x128, 4 waves) on 16x16x32
         default: return hipErrorInvalidValue;
     }
 }

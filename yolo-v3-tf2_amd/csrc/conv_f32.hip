@@ -76,6 +76,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         p.clk_stamps[0] = __builtin_amdgcn_s_memtime();
         p.clk_stamps[1] = __builtin_amdgcn_s_memrealtime();
     }
+    if (p.clk_stamps != nullptr && blockIdx.x == 0 && tid == 0) p.clk_stamps[4] = __builtin_amdgcn_s_memrealtime();   // the launch's first workgroup: when the kernel began
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
@@ -195,10 +196,20 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     // (SQ_VALU_MFMA_COEXEC_CYCLES == 0 in the profile), so the K loop must issue (almost) no vector ALU
     // instructions: per-lane byte offsets are fixed per tap (out-of-image lanes hold the out-of-range
     // sentinel) and everything that changes per K tile goes into the scalar soffset of the buffer load.
+    // K order.  Classic (k_chunk == 0): k = tap * Cin + c walked upwards.  Chunked (k_chunk = CK channels, 3x3 convs): for
+    // every chunk of CK input channels all taps, then the next chunk -- the SAME products summed in another order (weights stay
+    // packed [n][tap * Cin + c]; only the soffsets change).  The 9 reads of a pixel's CK channels (one per tap) then fall into
+    // 9 * CK / 32 consecutive K tiles instead of being Cin / 32 tiles apart, so the tap re-reads hit in L2: with the classic
+    // order a 512 -> 1024 @13 launch fetched 1.5-1.9 GB from beyond L2 for 85 MB of operands (tools/traffic_per_layer.py).
+    const int CK = (!CONCAT && !SK && p.k_chunk > 0 && p.k_chunk < p.Cin) ? p.k_chunk : p.Cin;
     int kglob = seg_k0 * BK;  // k index of the next tile to fetch
     int tap = CONCAT ? 0 : kglob / p.Cin;
     int c0 = kglob - tap * p.Cin;
+    int cend = CK;            // end of the current channel chunk (classic order: Cin)
+    const int taps = p.ksize * p.ksize;
     unsigned avoff[AP];                  // voffset of this lane's piece for the current tap (or OOB0)
+    unsigned okmask[CONCAT ? 1 : AP];    // !CONCAT: bit t = tap t of this row lies inside the image
+    unsigned abase4[CONCAT ? 1 : AP];    // !CONCAT: byte offset of this lane's piece of the row at tap (0, 0), channel 0
     unsigned avoff1[CONCAT ? AP : 1];    // CONCAT: same for src1
     auto set_tap = [&]() {
         if (CONCAT) {
@@ -208,16 +219,29 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                 avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)(aoff1[i] + lchunk) * 4u;
             }
         } else {
+            // 4 vector instructions per row (bit test, compare, add, select): with the chunk-major K order this runs every
+            // CK / 32 K tiles, and vector ALU time is lost MFMA time
             const int u = tap / p.ksize, v = tap - u * p.ksize;
-            const int toff = (u * p.W + v) * p.Cin + lchunk;
+            const unsigned toff4 = (unsigned)((u * p.W + v) * p.Cin) * 4u;
 #pragma unroll
-            for (int i = 0; i < AP; ++i) {
-                const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
-                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                avoff[i] = ok ? (unsigned)(aoff[i] + toff) * 4u : OOB0;
-            }
+            for (int i = 0; i < AP; ++i) avoff[i] = ((okmask[i] >> tap) & 1u) ? abase4[i] + toff4 : OOB0;
         }
     };
+    if (!CONCAT) {
+        // per row: bit t of okmask = tap t reads inside the image (rows >= M: no bit set); byte offset of the lane's piece at tap 0
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            unsigned mk = 0;
+            if (ahw[i] >= 0 || (ahw[i] >> 16) != -32768) {
+                const int hi0 = ahw[i] >> 16, wi0 = (int)(short)(ahw[i] & 0xffff);
+                for (int u = 0; u < p.ksize; ++u)
+                    for (int v = 0; v < p.ksize; ++v)
+                        if ((unsigned)(hi0 + u) < (unsigned)p.H && (unsigned)(wi0 + v) < (unsigned)p.W) mk |= 1u << (u * p.ksize + v);
+            }
+            okmask[i] = mk;
+            abase4[i] = (unsigned)(aoff[i] + lchunk) * 4u;
+        }
+    }
     set_tap();
 
     f32x4 ra[AP], rb[BP];
@@ -238,13 +262,17 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
         for (int j = 0; j < BP; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(sb + j * RP * LDS_ROW), 16, (int)boff[j], kglob * 4, 0, 0);
-        kglob += BK;
         c0 += BK;
-        if (c0 == p.Cin) {
-            c0 = 0;
+        if (c0 == cend) {
             ++tap;
+            if (!CONCAT && !SK && tap == taps && cend != p.Cin) {   // chunked order: next channel chunk, first tap again
+                tap = 0;
+                cend += CK;
+            }
+            c0 = cend - CK;
             if (!CONCAT) set_tap();
         }
+        kglob = tap * p.Cin + c0;
     };
     auto fetch = [&]() {
         if (CONCAT) {
@@ -262,13 +290,17 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) rb[j] = buf_load16(rsw, boff[j], kglob * 4);
-        kglob += BK;
         c0 += BK;
-        if (c0 == p.Cin) {
-            c0 = 0;
+        if (c0 == cend) {
             ++tap;
+            if (!CONCAT && !SK && tap == taps && cend != p.Cin) {   // chunked order: next channel chunk, first tap again
+                tap = 0;
+                cend += CK;
+            }
+            c0 = cend - CK;
             if (!CONCAT) set_tap();
         }
+        kglob = tap * p.Cin + c0;
     };
     auto stage = [&](int buf) {
         float *sa = smem + buf * STAGE;

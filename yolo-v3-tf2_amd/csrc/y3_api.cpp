@@ -121,8 +121,9 @@ struct y3_net {
     bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
     bool stem_conv2 = false;       // ... and the 1x1 conv that follows them (64 -> 32) runs inside it as well (fp32 plans)
     unsigned long long *clk_stamps = nullptr;   // y3_net_measure_sclk: device buffer one conv launch stamps into (else null)
-    int clk_conv = -1;                          // ... and which conv
+    int clk_conv = -1;                          // ... and which conv (-2: every conv, 8 words each at clk_stamps + 8 conv)
     int xcd_mode = 1;              // y3_net_set_xcd_mode: 0 contiguous tile runs per XCD, 1 XCD-blocked order chosen per conv
+    int k_chunk = -1;              // y3_net_set_k_chunk: fp32 3x3 convs walk K chunk-major, this many input channels per chunk; 0 tap-major; -1 per-conv default
     int sk_grid = 0;               // y3_net_set_sk_grid: > 0 overrides the number of persistent workgroups (tests)
     int cur_batch = 1;             // batch of the forward being enqueued
     hipEvent_t fork_ev = nullptr;
@@ -280,6 +281,17 @@ int choose_tile_bf16(const ConvSlot &c, long long M)
 // blocks.  An XCD then streams 1/gn of the weights and 1/gm of the activations; the L2-miss traffic of the launch is
 // about gn * (activation bytes) + gm * (weight bytes), provided an XCD's weight slice stays L2-resident (<= 2.5 MB) while
 // its workgroups walk the K loop.  0 = not applicable (tile count too small / not divisible).
+// channels per K chunk of a 3x3 fp32 conv when the caller has not chosen (y3_net_set_k_chunk(-1)); Y3_K_CHUNK overrides (tools)
+int default_k_chunk(const ConvSlot &c)
+{
+    static const int env = [] { const char *e = getenv("Y3_K_CHUNK"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env;
+    // 128 channels per chunk: traffic beyond L2 of the whole conv stack 42.1 -> 29.6 GB per 64-image step (1.96 x -> 1.42 x the
+    // algorithmic bytes) at the same images/s (-0.1 %, inside the run-to-run spread); 64 per chunk: 27.2 GB but -0.4 %
+    // (profiles/r03_k_chunk_sweep.txt, r03_traffic_per_layer_*.txt)
+    return (c.d.size == 3 && c.d.cin >= 256) ? 128 : 0;
+}
+
 int choose_xcd_gn(const ConvSlot &c, const y3::ConvArgs &a, const y3::TileInfo &t)
 {
     if (t.sk) return 0;
@@ -687,6 +699,13 @@ y3_status y3_net_set_stem_fusion(y3_net *net, int on)
     return Y3_OK;
 }
 
+y3_status y3_net_set_k_chunk(y3_net *net, int channels)
+{
+    if (!net || channels < -1 || (channels > 0 && channels % 32)) return fail(Y3_ERR_INVALID, "y3_net_set_k_chunk: -1, 0 or a multiple of 32 channels");
+    net->k_chunk = channels;
+    return Y3_OK;
+}
+
 y3_status y3_net_set_xcd_mode(y3_net *net, int mode)
 {
     if (!net || mode < 0 || mode > 1) return fail(Y3_ERR_INVALID, "y3_net_set_xcd_mode: mode must be 0 or 1");
@@ -977,7 +996,8 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.sk_cnt_cap = net->sk_cnt_cap;
             a.sk_grid_override = net->sk_grid;
             a.xcd_gn = 0;
-            a.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : nullptr;   // fp32 MFMA kernel and stem only
+            a.k_chunk = 0;
+            a.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : (net->clk_conv == -2 && net->clk_stamps) ? net->clk_stamps + 8 * o.index : nullptr;   // fp32 MFMA kernel and stem only
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if ((net->stem_fused && oi == 0) || (net->stem_conv2 && oi == 2)) {   // runs inside conv1's launch (fused stem)
                 if (ms_out && o.index < n_ms) ms_out[o.index] = 0.0f;
@@ -1002,7 +1022,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 sa.leaky1 = d.leaky;
                 sa.img_bytes = (unsigned)bytes(c0.d.src0);
                 sa.dst_bytes = a.dst_bytes;
-                sa.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : nullptr;
+                sa.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : (net->clk_conv == -2 && net->clk_stamps) ? net->clk_stamps + 8 * o.index : nullptr;
                 if (net->stem_conv2) {
                     const ConvSlot &c2 = net->convs[net->ops[2].index];
                     sa.w2 = c2.w_dev;
@@ -1045,6 +1065,10 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             } else {
                 const int tile = c.tile >= 0 ? c.tile : choose_tile(c, a.M);
                 if (net->xcd_mode) a.xcd_gn = choose_xcd_gn(c, a, y3::conv_tile_info(tile));
+                {   // K order of the 3x3 convs (conv_f32.hip): chunk-major when the conv has more input channels than one chunk
+                    const int ck = net->k_chunk >= 0 ? net->k_chunk : default_k_chunk(c);
+                    if (d.size == 3 && d.src1 < 0 && ck > 0 && d.cin > ck && d.cin % ck == 0 && ck % 32 == 0) a.k_chunk = ck;
+                }
                 e = y3::launch_conv_f32(a, tile, s);
             }
             if (e != hipSuccess) return fail(Y3_ERR_HIP, "conv %d launch: %s", o.index, hipGetErrorString(e));
@@ -1170,32 +1194,68 @@ y3_status y3_net_profile_convs(y3_net *net, const float *images_dev, int batch, 
     return st;
 }
 
+namespace {
+// can conv slot i of this plan carry the clock stamps?  The fp32 MFMA kernel (fp32 plans) and the fused stem kernel do.
+bool conv_carries_stamps(const y3_net *net, size_t i)
+{
+    const ConvSlot &c = net->convs[i];
+    const bool stem = net->stem_fused && net->ops.size() > 1 && net->ops[1].kind == 0 && net->ops[1].index == (int)i;
+    if (stem) return true;
+    if (net->stem_fused && (i == (size_t)net->ops[0].index || (net->stem_conv2 && net->ops.size() > 2 && i == (size_t)net->ops[2].index)))
+        return false;    // runs inside the stem launch
+    return net->dtype == Y3_DTYPE_F32 && !c.first_layer;
+}
+y3_status measure_sclk_impl(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
+                            int pick, float *mhz_out, void *stream);
+}  // namespace
+
+y3_status y3_net_measure_sclk_conv(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
+                                   int conv, float *mhz_out, void *stream)
+{
+    if (!net || !mhz_out || forwards < 1 || conv < 0 || conv >= (int)net->convs.size())
+        return fail(Y3_ERR_INVALID, "y3_net_measure_sclk_conv: bad argument");
+    if (!conv_carries_stamps(net, (size_t)conv))
+        return fail(Y3_ERR_STATE, "y3_net_measure_sclk_conv: the launch of conv %d carries no clock stamps in this plan", conv);
+    return measure_sclk_impl(net, images_dev, batch, grids_dev, forwards, conv, mhz_out, stream);
+}
+
 y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
                               float *mhz_out, void *stream)
 {
     if (!net || !mhz_out || forwards < 1) return fail(Y3_ERR_INVALID, "y3_net_measure_sclk: bad argument");
     // the launch that carries the stamps: the conv with the most FLOPs among those whose kernel has them -- the fp32 MFMA
-    // kernel (fp32 plans; workgroup 0 of a ~0.8 ms launch) or the fused stem kernel (fp32 and bf16 plans)
+    // kernel (fp32 plans; a steady-state workgroup of a ~0.8 ms launch) or the fused stem kernel (fp32 and bf16 plans)
     int pick = -1;
     double best = 0;
     for (size_t i = 0; i < net->convs.size(); ++i) {
         const ConvSlot &c = net->convs[i];
-        const bool stem = net->stem_fused && net->ops.size() > 1 && net->ops[1].kind == 0 && net->ops[1].index == (int)i;
-        if (!(stem || (net->dtype == Y3_DTYPE_F32 && !c.first_layer && !(net->stem_fused && i == (size_t)net->ops[0].index)))) continue;
+        if (!conv_carries_stamps(net, i)) continue;
         const double ho = net->image_size ? net->image_size / c.d.out_div : 0;
         const double fl = 2.0 * c.d.size * c.d.size * c.d.cin * c.d.cout * ho * ho;
         if (fl > best) { best = fl; pick = (int)i; }
     }
     if (pick < 0) return fail(Y3_ERR_STATE, "y3_net_measure_sclk: no launch of this plan carries clock stamps (fp32 plan or fused stem needed)");
+    return measure_sclk_impl(net, images_dev, batch, grids_dev, forwards, pick, mhz_out, stream);
+}
+
+namespace {
+// pick >= 0: that conv, *mhz_out one value; pick == -2: every conv that carries stamps, mhz_out / start_us / end_us arrays of
+// convs.size() entries (0 where a conv left no stamps; times relative to the earliest stamp, from s_memrealtime)
+y3_status measure_sclk_arrays(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
+                              int pick, float *mhz_out, double *start_us, double *end_us, void *stream)
+{
     HIP_TRY(hipSetDevice(net->device));
-    unsigned long long *buf = nullptr, host[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), sizeof(host)));
-    // the chip's clock follows the load of the last milliseconds: stamp the stem kernel of the LAST of `forwards`
-    // back-to-back forwards, unstamped ones first
+    const size_t nconv = net->convs.size();
+    const size_t words = pick == -2 ? 8 * nconv : 8;   // per conv: memtime, realtime at entry; the same after the epilogue; realtime at the entry of workgroup 0
+    std::vector<unsigned long long> host(words, 0ull);
+    unsigned long long *buf = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&buf), words * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(buf, 0, words * sizeof(unsigned long long), (hipStream_t)stream);
+    // the chip's clock follows the load of the last milliseconds: stamp the LAST of `forwards` back-to-back forwards
     y3_status st = Y3_OK;
     const int lanes_saved = net->lanes;
-    net->lanes = 1;             // one launch of the stamped conv (concurrent sub-batches would each stamp the same words)
-    for (int i = 0; i < forwards && st == Y3_OK; ++i) {
+    net->lanes = 1;             // one launch of a stamped conv (concurrent sub-batches would each stamp the same words)
+    for (int i = 0; i < forwards && st == Y3_OK && e == hipSuccess; ++i) {
         net->clk_stamps = (i == forwards - 1) ? buf : nullptr;
         net->clk_conv = (i == forwards - 1) ? pick : -1;
         st = run(net, images_dev, batch, grids_dev, (hipStream_t)stream, nullptr, 0);
@@ -1203,15 +1263,47 @@ y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, f
     net->clk_stamps = nullptr;
     net->clk_conv = -1;
     net->lanes = lanes_saved;
-    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-    if (e == hipSuccess) e = hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpy(host.data(), buf, words * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(buf);
     if (st != Y3_OK) return st;
     if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_measure_sclk: %s", hipGetErrorString(e));
-    const double ticks = (double)(host[2] - host[0]), real = (double)(host[3] - host[1]);
-    if (!(real > 0.0) || !(ticks > 0.0)) return fail(Y3_ERR_STATE, "y3_net_measure_sclk: conv %d left no stamps", pick);
-    *mhz_out = (float)(ticks / real * 100.0);   // s_memrealtime counts at 100 MHz
+    if (pick >= 0) {
+        const double ticks = (double)(host[2] - host[0]), real = (double)(host[3] - host[1]);
+        if (!(real > 0.0) || !(ticks > 0.0)) return fail(Y3_ERR_STATE, "y3_net_measure_sclk: conv %d left no stamps", pick);
+        *mhz_out = (float)(ticks / real * 100.0);   // s_memrealtime counts at 100 MHz
+        return Y3_OK;
+    }
+    // start = entry of the launch's FIRST workgroup (word 4; the stem kernel stamps in workgroup 0 throughout: word 1),
+    // end = after the epilogue of the clock-stamped workgroup (a middle one; the stem: workgroup 0, resident to the end)
+    auto first = [&](size_t c) { return host[8 * c + 4] ? host[8 * c + 4] : host[8 * c + 1]; };
+    unsigned long long t0 = ~0ull;
+    for (size_t c = 0; c < nconv; ++c)
+        if (host[8 * c + 3] > host[8 * c + 1] && first(c) < t0) t0 = first(c);
+    int stamped = 0;
+    for (size_t c = 0; c < nconv; ++c) {
+        const double ticks = (double)(host[8 * c + 2] - host[8 * c]), real = (double)(host[8 * c + 3] - host[8 * c + 1]);
+        const bool ok = host[8 * c + 3] > host[8 * c + 1] && host[8 * c + 2] > host[8 * c];
+        mhz_out[c] = ok ? (float)(ticks / real * 100.0) : 0.0f;
+        if (start_us) start_us[c] = ok ? (double)(first(c) - t0) / 100.0 : 0.0;
+        if (end_us) end_us[c] = ok ? (double)(host[8 * c + 3] - t0) / 100.0 : 0.0;
+        stamped += ok;
+    }
+    if (!stamped) return fail(Y3_ERR_STATE, "y3_net_measure_sclk_all: no launch of this plan left clock stamps (fp32 plan or fused stem needed)");
     return Y3_OK;
+}
+y3_status measure_sclk_impl(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
+                            int pick, float *mhz_out, void *stream)
+{
+    return measure_sclk_arrays(net, images_dev, batch, grids_dev, forwards, pick, mhz_out, nullptr, nullptr, stream);
+}
+}  // namespace
+
+y3_status y3_net_measure_sclk_all(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
+                                  float *mhz_out, double *start_us, double *end_us, void *stream)
+{
+    if (!net || !mhz_out || forwards < 1) return fail(Y3_ERR_INVALID, "y3_net_measure_sclk_all: bad argument");
+    return measure_sclk_arrays(net, images_dev, batch, grids_dev, forwards, -2, mhz_out, start_us, end_us, stream);
 }
 
 y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size_t *n_elems, void *stream)

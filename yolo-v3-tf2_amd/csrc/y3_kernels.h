@@ -36,6 +36,7 @@ struct ConvArgs {
     // fp32 classic schedule: 0 = every XCD takes a contiguous run of tiles (N fastest); gn in {1,2,4,8} = the XCDs form
     // an (8/gn) x gn grid over the (M-tile, N-tile) matrix (see conv_f32.hip)
     int xcd_gn;
+    int k_chunk;           // fp32 MFMA kernel, 3x3 convs: > 0 walks K chunk-major, k_chunk input channels at a time (conv_f32.hip); 0: tap-major
     // measurement only (y3_net_measure_sclk): when non-null, thread 0 of the middle workgroup stores {s_memtime, s_memrealtime}
     // at its entry and after its epilogue -> the shader clock held while that workgroup ran.  Null in every product launch.
     unsigned long long *clk_stamps;   // [4]
@@ -95,7 +96,7 @@ hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s);
 hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s);   // conv0 in fp32 arithmetic, bf16 patch, conv1 on bf16 MFMA
 
 // bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
-static constexpr int BF16_TILE_COUNT = 21;
+static constexpr int BF16_TILE_COUNT = 30;
 TileInfo conv_bf16_tile_info(int tile);
 bool conv_bf16_tile_built(int tile);
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);

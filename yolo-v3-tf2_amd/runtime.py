@@ -105,6 +105,10 @@ class Net:
         """fp32 conv tile placement on the 8 XCDs: 1 = XCD-blocked order chosen per conv (default), 0 = contiguous runs."""
         check(self.lib.y3_net_set_xcd_mode(self._h, int(mode)), "y3_net_set_xcd_mode")
 
+    def set_k_chunk(self, channels: int):
+        """K order of the fp32 3x3 convs: channels per chunk (multiple of 32) walked chunk-major, 0 tap-major, -1 default."""
+        check(self.lib.y3_net_set_k_chunk(self._h, int(channels)), "y3_net_set_k_chunk")
+
     def set_stem_fusion(self, on: bool):
         """conv0 + conv1 as one kernel (default on; applies when the program starts with the Darknet-53 stem and the plan
         is fp32 without keep_activations)."""
@@ -219,15 +223,34 @@ class Net:
 
     __call__ = forward
 
-    def measure_sclk(self, images: torch.Tensor, out: Sequence[torch.Tensor], forwards: int = 30) -> float:
-        """Shader clock (MHz) the chip holds under this network's load: `forwards` forwards back to back, the last one's
-        fused stem kernel stamps s_memtime / s_memrealtime (y3_net_measure_sclk).  Raises when the plan has no stem kernel."""
+    def measure_sclk(self, images: torch.Tensor, out: Sequence[torch.Tensor], forwards: int = 30, conv: int = -1) -> float:
+        """Shader clock (MHz) the chip holds under this network's load: `forwards` forwards back to back, in the last one
+        a conv launch stamps s_memtime / s_memrealtime (y3_net_measure_sclk: the conv with the most FLOPs; conv >= 0:
+        that conv slot, y3_net_measure_sclk_conv).  Raises when no launch of the plan / not that launch carries stamps."""
         _need_cuda(images, *out)
         ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in out])
         mhz = C.c_float()
-        check(self.lib.y3_net_measure_sclk(self._h, _dev(images), images.shape[0], ptrs, int(forwards), C.byref(mhz),
-                                           _lib.stream_ptr()), "y3_net_measure_sclk")
+        if conv >= 0:
+            check(self.lib.y3_net_measure_sclk_conv(self._h, _dev(images), images.shape[0], ptrs, int(forwards), int(conv),
+                                                    C.byref(mhz), _lib.stream_ptr()), "y3_net_measure_sclk_conv")
+        else:
+            check(self.lib.y3_net_measure_sclk(self._h, _dev(images), images.shape[0], ptrs, int(forwards), C.byref(mhz),
+                                               _lib.stream_ptr()), "y3_net_measure_sclk")
         return float(mhz.value)
+
+    def measure_sclk_all(self, images: torch.Tensor, out: Sequence[torch.Tensor], forwards: int = 30):
+        """Per conv slot: (MHz, start_us, end_us) of the stamped workgroup of its launch in the last of `forwards`
+        back-to-back forwards (y3_net_measure_sclk_all); MHz 0 where a conv leaves no stamps.  numpy arrays."""
+        import numpy as np
+        _need_cuda(images, *out)
+        ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in out])
+        n = len(self.conv_ops)
+        mhz = (C.c_float * n)()
+        t0 = (C.c_double * n)()
+        t1 = (C.c_double * n)()
+        check(self.lib.y3_net_measure_sclk_all(self._h, _dev(images), images.shape[0], ptrs, int(forwards), mhz, t0, t1,
+                                               _lib.stream_ptr()), "y3_net_measure_sclk_all")
+        return np.array(mhz[:], dtype=np.float64), np.array(t0[:]), np.array(t1[:])
 
     def read_tensor(self, tensor_id: int, batch: int) -> torch.Tensor:
         n = C.c_size_t()
