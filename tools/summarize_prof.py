@@ -97,8 +97,10 @@ def main(out):
     if agg:
         import json
         conv = [k for k in agg if k.startswith("conv_")]
-        first = [k for k in conv if "first" in k or "stem" in k]   # launched once per step
-        steps = max(calls[k] for k in first) if first else 1
+        # steps of the run: the NMS kernel runs once per step whatever the number of sub-batch lanes (the first conv / the
+        # stem kernel run once per LANE: counting those halved the bf16 figure of the two-lane plan until round 3)
+        once = [k for k in calls if k.startswith("nms_kernel")] or [k for k in conv if "first" in k or "stem" in k]
+        steps = max(calls[k] for k in once) if once else 1
         fetch = sum(agg[k].get("FETCH_SIZE", 0) for k in conv) * 1024 * 2 / steps
         write = sum(agg[k].get("WRITE_SIZE", 0) for k in conv) * 1024 / steps
         with open(os.path.join(out, "summary_traffic.json"), "w") as o:

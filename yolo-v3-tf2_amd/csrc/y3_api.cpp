@@ -255,6 +255,10 @@ int choose_tile_x3(const ConvSlot &c, long long M)
 
 int choose_tile_bf16(const ConvSlot &c, long long M)
 {
+    // large 3x3 convs: the 256x256 tile of 16 waves on 16x16x32 MFMAs once it fills the chip (tile 24 wins every such
+    // signature of the 64- and 128-image tables, tuning/bf16_b*_s416.json)
+    if (c.d.size == 3 && c.d.src1 < 0 && c.d.cin % 64 == 0 && c.cout_pad % 256 == 0 && ((M + 255) / 256) * (c.cout_pad / 256) >= 256)
+        return 24;
     std::vector<int> cand;
     if (c.d.cin % 64)
         cand = {5, 6};                       // BK = 32 (Cin = 32 layers, Cout = 64)
@@ -277,10 +281,6 @@ int choose_tile_bf16(const ConvSlot &c, long long M)
     return best;
 }
 
-// How the 8 XCDs (each with its own 4 MB L2) divide the tile matrix of one fp32 conv launch: as a (8/gn) x gn grid of
-// blocks.  An XCD then streams 1/gn of the weights and 1/gm of the activations; the L2-miss traffic of the launch is
-// about gn * (activation bytes) + gm * (weight bytes), provided an XCD's weight slice stays L2-resident (<= 2.5 MB) while
-// its workgroups walk the K loop.  0 = not applicable (tile count too small / not divisible).
 // channels per K chunk of a 3x3 fp32 conv when the caller has not chosen (y3_net_set_k_chunk(-1)); Y3_K_CHUNK overrides (tools)
 int default_k_chunk(const ConvSlot &c)
 {
@@ -292,6 +292,10 @@ int default_k_chunk(const ConvSlot &c)
     return (c.d.size == 3 && c.d.cin >= 256) ? 128 : 0;
 }
 
+// How the 8 XCDs (each with its own 4 MB L2) divide the tile matrix of one fp32 conv launch: as a (8/gn) x gn grid of
+// blocks.  An XCD then streams 1/gn of the weights and 1/gm of the activations; the L2-miss traffic of the launch is
+// about gn * (activation bytes) + gm * (weight bytes), provided an XCD's weight slice stays L2-resident (<= 2.5 MB) while
+// its workgroups walk the K loop.  0 = not applicable (tile count too small / not divisible).
 int choose_xcd_gn(const ConvSlot &c, const y3::ConvArgs &a, const y3::TileInfo &t)
 {
     if (t.sk) return 0;

@@ -168,7 +168,7 @@ class Net:
         from . import PACKAGE_DIR
         tag = _lib.DTYPE_TAGS[self.dtype]
         name = f"{tag}_b{self.max_batch}_s{self.image_size}.json"
-        path = os.path.join(PACKAGE_DIR, "tuning", name)
+        path = os.environ.get("Y3_TUNING_FILE") or os.path.join(PACKAGE_DIR, "tuning", name)   # the override: A/B of tables (tools)
         kind, fn = {_lib.Y3_DTYPE_F32: ("", self.lib.y3_net_set_tile), _lib.Y3_DTYPE_BF16: ("_bf16", self.lib.y3_net_set_tile_bf16),
                     _lib.Y3_DTYPE_F32X3: ("_x3", self.lib.y3_net_set_tile_x3),
                     _lib.Y3_DTYPE_F32X2: ("_x2", self.lib.y3_net_set_tile_x2)}[self.dtype]
