@@ -309,9 +309,22 @@ def main():
     sclk_mhz, sclk_src = None, None
     if rank == 0:
         try:
-            sclk_mhz = net.measure_sclk(images, grids, forwards=max(10, int(1000.0 / max(1.0, dt / args.steps * 1e3))))
-            sclk_src = ("s_memtime / s_memrealtime stamps inside the largest conv launch after ~1 s of back-to-back forwards "
-                        "(y3_net_measure_sclk; sysfs and rocm-smi report the DPM level, not the clock held at the power cap)")
+            fw = max(10, int(1000.0 / max(1.0, dt / args.steps * 1e3)))
+            mhz, t_start, t_end = net.measure_sclk_all(images, grids, forwards=fw)
+            idx = [i for i in range(len(mhz)) if mhz[i] > 0]
+            if len(idx) > 1:
+                # every conv launch of the last forward carries stamps: weight each launch's clock with its duration on the
+                # chip's own timeline (start of the next stamped launch - its start; the last one: its stamped workgroup)
+                dur = [(t_start[idx[k + 1]] if k + 1 < len(idx) else t_end[i]) - t_start[i] for k, i in enumerate(idx)]
+                sclk_mhz = float(sum(mhz[i] * d for i, d in zip(idx, dur)) / sum(dur))
+                sclk_src = (f"time-weighted mean over the {len(idx)} conv launches of one forward ({min(mhz[i] for i in idx):.0f}-"
+                            f"{max(mhz[i] for i in idx):.0f} MHz), each from s_memtime / s_memrealtime stamps of a steady-state "
+                            "workgroup, after ~1 s of back-to-back forwards (y3_net_measure_sclk_all; sysfs and rocm-smi "
+                            "report the DPM level, not the clock held at the power cap)")
+            else:
+                sclk_mhz = float(mhz[idx[0]])
+                sclk_src = ("s_memtime / s_memrealtime stamps inside the fused stem launch (the only kernel of this plan that "
+                            "carries stamps) after ~1 s of back-to-back forwards (y3_net_measure_sclk_all)")
         except runtime.Y3Error as e:
             sclk_src = f"not measured: {e}"
     if use_dist:

@@ -1742,3 +1742,57 @@ def test_measure_sclk_reads_a_plausible_clock(rt, program, weights):
     net.set_stem_fusion(False)      # a bf16 plan without the stem kernel has no launch that carries stamps
     with pytest.raises(rt.Y3Error, match="stamps"):
         net.measure_sclk(x, g, forwards=2)
+
+
+def test_measure_sclk_per_conv_and_timeline(rt, program, weights):
+    """y3_net_measure_sclk_conv / _all: every launch of an fp32 plan stamps; the convs inside the fused stem launch do not;
+    starts are ordered like the launches and every stamped launch ends after it starts."""
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(8, 96)
+    x = torch.rand((8, 96, 96, 3), device="cuda")
+    g = [t.clone() for t in net.forward(x)]
+    scratch = [torch.empty_like(t) for t in g]
+    mhz, t0, t1 = net.measure_sclk_all(x, scratch, forwards=5)
+    n = len(net.conv_ops)
+    assert len(mhz) == n
+    stamped = [i for i in range(n) if mhz[i] > 0]
+    assert 0 not in stamped and 2 not in stamped and 1 in stamped          # conv0 and conv2 run inside conv1's launch
+    assert stamped == [1] + list(range(3, n))
+    assert all(100.0 < mhz[i] < 2600.0 for i in stamped), mhz
+    assert all(t1[i] > t0[i] for i in stamped)
+    assert all(t0[a] <= t0[b] for a, b in zip(stamped, stamped[1:]))      # one stream: launches start in program order
+    one = net.measure_sclk(x, scratch, forwards=5, conv=stamped[5])
+    assert 100.0 < one < 2600.0
+    with pytest.raises(rt.Y3Error, match="stamps"):
+        net.measure_sclk(x, scratch, forwards=2, conv=0)
+    assert all(torch.equal(a, b) for a, b in zip(g, net.forward(x)))       # measurement launches leave no trace
+
+
+@pytest.mark.parametrize("chunk", [32, 64, 128])
+def test_chunk_major_k_order_matches_oracle_and_tap_major(rt, chunk):
+    """y3_net_set_k_chunk: the fp32 3x3 convs summed chunk-major (all taps of `chunk` input channels, then the next chunk)
+    give the oracle's values within fp32 rounding, like the tap-major order, for stride 1 and 2, with a shortcut, at an
+    image size whose tiles straddle rows and images; chunk sizes that do not divide Cin leave the order tap-major."""
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from oracle import oracle as O
+    p = mini_program(256, [dict(filters=128, size=1), dict(filters=256, size=3, shortcut=-3), dict(filters=384, size=3, stride=2)],
+                     [dict(filters=64, size=3), dict(filters=64, size=1), dict(filters=64, size=1)])
+    w = synthetic_weights(p, seed=21)
+    x = np.random.default_rng(21).standard_normal((3, 14, 14, 256)).astype(np.float32)
+    ref = O.forward(p, w, x)
+    outs = {}
+    for ck in (0, chunk):
+        net = rt.Net(p)
+        net.load_weights(w)
+        net.set_k_chunk(ck)
+        net.plan(3, 14)
+        outs[ck] = [t.cpu().numpy() for t in net.forward(_cuda(x))]
+        torch.cuda.synchronize()
+        for r, g in zip(ref, outs[ck]):
+            assert np.abs(g.reshape(r.shape) - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
+    # the two orders are different summations of the same products: equal to rounding, and (for these sizes) not bit-equal
+    assert any(not np.array_equal(a, b) for a, b in zip(outs[0], outs[chunk]))
+    with pytest.raises(rt.Y3Error):
+        rt.Net(p).set_k_chunk(48)
