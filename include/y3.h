@@ -138,9 +138,10 @@ y3_status y3_net_set_xcd_mode(y3_net *net, int mode);
 y3_status y3_net_set_k_chunk(y3_net *net, int channels);
 y3_status y3_net_keep_activations(y3_net *net, int keep);
 /* 1 (default): when the program starts with conv0 (3x3/1, 3 -> 32) feeding only conv1 (3x3/2, 32 -> 64) -- the Darknet-53
- * stem, reference config/models/yolov3/backbone.yaml layers 1-2 -- and the plan is fp32 without keep_activations, the two
- * run as ONE kernel that keeps conv0's output (the largest tensor of the network, 1.4 GB at 64 x 416^2) in LDS; in fp32
- * plans the 1x1 conv that follows (64 -> 32, backbone.yaml layer 3) is computed by the same kernel from conv1's tile.
+ * stem, reference config/models/yolov3/backbone.yaml layers 1-2 -- and the plan is fp32 or bf16 without keep_activations,
+ * the two run as ONE kernel that keeps conv0's output (the largest tensor of the network, 1.4 GB at 64 x 416^2) in LDS; the
+ * 1x1 conv that follows (64 -> 32, backbone.yaml layer 3) is computed by the same kernel from conv1's tile.
+ * 2: conv0 + conv1 in one kernel, the 1x1 conv as its own launch (bf16 plans: bit-identical to 1).
  * 0: one launch per conv.  Results agree to fp32 rounding (conv0's summation order differs between the two kernels). */
 y3_status y3_net_set_stem_fusion(y3_net *net, int on);
 /* Measurement aid (bench.py): the shader clock the chip holds under this network's load.  Runs `forwards` forwards back to

@@ -1686,6 +1686,47 @@ def test_fused_stem_matches_oracle_and_the_two_launch_form(rt, S, B):
 
 
 @pytest.mark.parametrize("S,B", [(32, 1), (64, 3), (416, 2)])
+def test_fused_stem_bf16_third_layer_bit_identical_to_its_own_launch(rt, S, B):
+    """bf16 plans: the 1x1 conv that follows conv1 (64 -> 32, backbone.yaml layer 3; reference core/parse_model.py:27-52) is
+    computed by the stem kernel from conv1's staged bf16 tile (phase 3 of conv_stem_bf16).  Same operands, same MFMA
+    instruction and k grouping as the stand-alone conv_bf16_mfma launch: stem mode 1 (three layers in one kernel) must equal
+    mode 2 (conv0 + conv1 fused, the 1x1 launched on its own) bit for bit on every head, the 1x1 must report no launch of its own
+    in mode 1, and both stay within the free-running bf16 bar of the oracle."""
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    p = mini_program(3, [dict(filters=32, size=3), dict(filters=64, size=3, stride=2), dict(filters=32, size=1),
+                         dict(filters=64, size=3, shortcut=-3)],
+                     [dict(filters=32, size=1, bn=False, act="linear"), dict(filters=32, size=1, bn=False, act="linear"),
+                      dict(filters=64, size=1)])
+    w = synthetic_weights(p, seed=13)
+    x = np.random.default_rng(13).random((B, S, S, 3), dtype=np.float32)
+    ref = O.forward(p, w, x, bf16=True)
+    xd = _cuda(x)
+    outs = {}
+    for mode in (1, 2):
+        net = rt.Net(p)
+        net.load_weights(w)
+        net.plan(B, S, _lib.Y3_DTYPE_BF16)
+        net.set_lanes(1)
+        net.set_stem_fusion(mode)
+        got = [g.clone() for g in net.forward(xd)]
+        ms = net.profile_convs(xd)
+        assert ms[0] == 0.0, "fused stem did not engage"
+        assert (ms[2] == 0.0) == (mode == 1), "the 1x1 third layer: wrong launch structure for this mode"
+        outs[mode] = got
+        for r, g in zip(ref, got):
+            g = g.cpu().numpy().reshape(r.shape)
+            scale = max(1.0, float(np.abs(r).max()))
+            assert np.abs(g - r).max() <= 8e-3 * scale and np.abs(g - r).mean() <= 4e-4 * scale, \
+                (mode, float(np.abs(g - r).max()), float(np.abs(g - r).mean()))
+        again = net.forward(xd)
+        assert all(torch.equal(a, b) for a, b in zip(got, again))
+    assert all(torch.equal(a, b) for a, b in zip(outs[1], outs[2])), "phase 3 differs from the stand-alone 1x1 launch"
+
+
+@pytest.mark.parametrize("S,B", [(32, 1), (64, 3), (416, 2)])
 def test_fused_stem_bf16_matches_oracle_and_the_two_launch_form(rt, S, B):
     """The bf16 form of the fused stem (config 5): conv0 in fp32 arithmetic rounded to bf16 into the LDS patch, conv1 on
     the bf16 matrix cores.  conv1's output feeds three linear 1x1 heads whose fp32 outputs are compared (a) with the

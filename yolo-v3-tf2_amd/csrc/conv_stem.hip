@@ -152,7 +152,7 @@ __global__ __launch_bounds__(stem::NT, 1) void conv_stem_f32(const StemArgs p)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) w2f[t][s] = *reinterpret_cast<const f32x4 *>(p.w2 + (l15 + 16 * t) * C1 + 16 * s + 4 * lq);
+            for (int s = 0; s < 4; ++s) w2f[t][s] = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(p.w2) + (l15 + 16 * t) * C1 + 16 * s + 4 * lq);
             sh2[t] = p.shift2[l15 + 16 * t];
         }
     }
@@ -424,6 +424,10 @@ __global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
     const float sc0 = p.scale0[fr], sh0 = p.shift0[fr];
     const int wm = wave >> 1, wn = wave & 1;
     const float sc1 = p.scale1[wn * 32 + fr], sh1 = p.shift1[wn * 32 + fr];
+    const bool with2 = p.w2 != nullptr;      // wave-uniform: the 1x1 conv after conv1 runs from the staging tile (phase 3)
+    const float sc2 = with2 ? p.scale2[fr] : 0.0f, sh2 = with2 ? p.shift2[fr] : 0.0f;
+    constexpr int OUT2_OFF = 128 * 128;      // second staging tile, behind the first (both inside the dead patch region)
+    static_assert(OUT2_OFF + 128 * 64 <= PATCH_B, "staging tiles must fit the patch region");
 
     const int a1lo = PATCH_B + W1_B + (2 * wave * IW * 3 + fr * 3 + 105 * fh) * 4;
     const int a1hi = PATCH_B + W1_B + (2 * wave * IW * 3 + fr * 3 + 210 + 5 * fh) * 4;
@@ -597,6 +601,39 @@ __global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
                 const u32x4s v = *reinterpret_cast<const u32x4s *>(lds + P * 128 + ch * 16);
                 const int oy = ty * TH + (P >> 4), ox = tx * TW + (P & 15);
                 *reinterpret_cast<u32x4s *>(dst + ((size_t)(b * So + oy) * So + ox) * C1 + ch * 8) = v;
+            }
+        }
+        if (with2) {
+            // ---- phase 3: the 1x1 conv that follows conv1 (64 -> 32), from the staging tile = conv1's output as stored (bf16) ----
+            // waves 0..3: one 32-pixel block each, K = 64 = four steps of v_mfma_f32_32x32x16_bf16 in the k grouping of
+            // conv_bf16_mfma (lane half h takes k = 16 s + 8 h .. + 7): bit-identical to the separate launch.  Weights
+            // ([32][64] bf16, 4 KB, L1-resident) are fetched per tile: the kernel has no registers to keep them (118 of 128).
+            if (wave < 4) {
+                f32x16 acc2;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
+                const unsigned short *w2 = static_cast<const unsigned short *>(p.w2);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(lds + (wave * 32 + fr) * 128 + (2 * s + fh) * 16);
+                    const bf16x8 fb = *reinterpret_cast<const bf16x8 *>(w2 + fr * C1 + (2 * s + fh) * 8);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc2, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    float v = acc2[e] * sc2 + sh2;
+                    if (p.leaky2) v = fmaxf(v, 0.1f * v);
+                    *reinterpret_cast<unsigned short *>(lds + OUT2_OFF + (wave * 32 + m) * 64 + fr * 2) = bf16_bits(v);
+                }
+            }
+            __syncthreads();   // (3b) second staging tile ([128 pixels][32 channels] bf16) complete
+            {
+                unsigned short *dst2 = static_cast<unsigned short *>(p.dst2);
+                const int P = tid >> 2, ch = tid & 3;               // 512 chunks of 16 B
+                const u32x4s v = *reinterpret_cast<const u32x4s *>(lds + OUT2_OFF + P * 64 + ch * 16);
+                const int oy = ty * TH + (P >> 4), ox = tx * TW + (P & 15);
+                *reinterpret_cast<u32x4s *>(dst2 + ((size_t)(b * So + oy) * So + ox) * 32 + ch * 8) = v;
             }
         }
         if (next < p.n_tiles) img_stage();

@@ -117,9 +117,10 @@ struct y3_net {
     int *sk_cnt = nullptr;
     size_t sk_ws_lane_bytes = 0;
     int sk_cnt_cap = 0;
-    int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 as one kernel when the graph allows it
+    int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 (+ the 1x1 after them) as one kernel when the graph allows it; 2 = conv0 + conv1 only
+    bool stem_mode_set = false;    // y3_net_set_stem_fusion was called (the Y3_STEM_MODE tool override then stays out)
     bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
-    bool stem_conv2 = false;       // ... and the 1x1 conv that follows them (64 -> 32) runs inside it as well (fp32 plans)
+    bool stem_conv2 = false;       // ... and the 1x1 conv that follows them (64 -> 32) runs inside it as well (fp32 and bf16 plans)
     unsigned long long *clk_stamps = nullptr;   // y3_net_measure_sclk: device buffer one conv launch stamps into (else null)
     int clk_conv = -1;                          // ... and which conv (-2: every conv, 8 words each at clk_stamps + 8 conv)
     int xcd_mode = 1;              // y3_net_set_xcd_mode: 0 contiguous tile runs per XCD, 1 XCD-blocked order chosen per conv
@@ -370,10 +371,10 @@ static bool stem_applicable(const y3_net *net)
 }
 
 // third op = 1x1 conv 64 -> 32 reading conv1's output (backbone.yaml layer 3): computed by the stem kernel from the tile it
-// still holds on chip (fp32 plans)
+// still holds on chip (fp32 and bf16 plans)
 static bool stem_conv2_applicable(const y3_net *net)
 {
-    if (net->dtype != Y3_DTYPE_F32 || net->ops.size() < 3 || net->ops[2].kind != 0) return false;
+    if ((net->dtype != Y3_DTYPE_F32 && net->dtype != Y3_DTYPE_BF16) || net->ops.size() < 3 || net->ops[2].kind != 0) return false;
     const y3_conv_desc &b = net->convs[net->ops[1].index].d, &c = net->convs[net->ops[2].index].d;
     if (c.size != 1 || c.stride != 1 || c.cin != 64 || c.cout != 32 || c.residual >= 0 || c.src1 >= 0 || c.src0 != b.dst) return false;
     for (int k = 0; k < 3; ++k)
@@ -693,12 +694,13 @@ y3_status y3_net_set_lanes(y3_net *net, int lanes)
 
 y3_status y3_net_set_stem_fusion(y3_net *net, int on)
 {
-    if (!net || on < 0 || on > 1) return fail(Y3_ERR_INVALID, "y3_net_set_stem_fusion: argument must be 0 or 1");
+    if (!net || on < 0 || on > 2) return fail(Y3_ERR_INVALID, "y3_net_set_stem_fusion: argument must be 0, 1 or 2");
     net->stem_mode = on;
+    net->stem_mode_set = true;
     // takes effect at once on a planned net when the graph qualifies (decided again by the next y3_net_plan)
     if (net->image_size) {
         net->stem_fused = on && stem_applicable(net);
-        net->stem_conv2 = net->stem_fused && stem_conv2_applicable(net);
+        net->stem_conv2 = net->stem_fused && on == 1 && stem_conv2_applicable(net);
     }
     return Y3_OK;
 }
@@ -869,8 +871,12 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
                 return st;
             }
     }
+    {   // Y3_STEM_MODE (tools: same-process-tree A/B of the stem forms) overrides the default, not an explicit setter call
+        static const int env = [] { const char *e = getenv("Y3_STEM_MODE"); return e ? atoi(e) : -1; }();
+        if (env >= 0 && env <= 2 && !net->stem_mode_set) net->stem_mode = env;
+    }
     net->stem_fused = net->stem_mode && stem_applicable(net);
-    net->stem_conv2 = net->stem_fused && stem_conv2_applicable(net);
+    net->stem_conv2 = net->stem_fused && net->stem_mode == 1 && stem_conv2_applicable(net);
     if (net->nclasses > 0) {   // scratch of y3_net_detect: no allocation inside the stream-ordered call
         size_t off[9], n_boxes, gelems[3];
         int32_t gs[3];
@@ -1029,7 +1035,8 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 sa.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : (net->clk_conv == -2 && net->clk_stamps) ? net->clk_stamps + 8 * o.index : nullptr;
                 if (net->stem_conv2) {
                     const ConvSlot &c2 = net->convs[net->ops[2].index];
-                    sa.w2 = c2.w_dev;
+                    sa.w2 = bf ? c2.wbf_dev : static_cast<const void *>(c2.w_dev);
+                    sa.scale2 = c2.scale_dev;
                     sa.shift2 = c2.shift_dev;
                     sa.dst2 = ptr(c2.d.dst);
                     sa.leaky2 = c2.d.leaky;

@@ -76,11 +76,12 @@ struct StemArgs {
     const float *scale1;   // [64]  (bf16 kernel only)
     const float *shift1;   // [64]
     void *dst;             // [B,S/2,S/2,64] fp32 / bf16
-    // optional third layer (fp32 kernel): the 1x1 conv reading conv1's output (64 -> 32, BN, leaky), computed from the tile
+    // optional third layer: the 1x1 conv reading conv1's output (64 -> 32, BN, leaky), computed from the tile
     // while it is still on chip.  w2 = nullptr: absent.
-    const float *w2;       // packed [32][64] fp32, BN scale folded in
+    const void *w2;        // packed [32][64]: fp32 with the BN scale folded in / bf16 unscaled
+    const float *scale2;   // [32]  (bf16 kernel only)
     const float *shift2;   // [32]
-    void *dst2;            // [B,S/2,S/2,32] fp32
+    void *dst2;            // [B,S/2,S/2,32] fp32 / bf16
     int leaky2;
     unsigned dst2_bytes;
     int B, S;              // S % 32 == 0

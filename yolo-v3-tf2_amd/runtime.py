@@ -109,10 +109,10 @@ class Net:
         """K order of the fp32 3x3 convs: channels per chunk (multiple of 32) walked chunk-major, 0 tap-major, -1 default."""
         check(self.lib.y3_net_set_k_chunk(self._h, int(channels)), "y3_net_set_k_chunk")
 
-    def set_stem_fusion(self, on: bool):
-        """conv0 + conv1 as one kernel (default on; applies when the program starts with the Darknet-53 stem and the plan
-        is fp32 without keep_activations)."""
-        check(self.lib.y3_net_set_stem_fusion(self._h, int(bool(on))), "y3_net_set_stem_fusion")
+    def set_stem_fusion(self, on):
+        """conv0 + conv1 (+ the 1x1 conv that follows them) as one kernel (default on; applies when the program starts with
+        the Darknet-53 stem and the plan is fp32 or bf16 without keep_activations).  2: conv0 + conv1 only."""
+        check(self.lib.y3_net_set_stem_fusion(self._h, int(on)), "y3_net_set_stem_fusion")
 
     def set_sk_grid(self, workgroups: int):
         """Number of persistent workgroups of the stream-K conv tiles (0 = everything resident at once)."""
