@@ -418,9 +418,26 @@ __global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
             *reinterpret_cast<u32x4s *>(lds + PATCH_B + n * (K1 * 2) + kp * 16) = v;
         }
     }
-    float b0[14];
+    // conv0 on the bf16 matrix cores with fp32-class accuracy: image values and weights are split x = hi + lo (two bf16, 16
+    // significand bits together) and a product is formed as hi*hi + hi*lo + lo*hi with fp32 accumulation (the dropped lo*lo is
+    // <= 2^-18 of the product): 6 v_mfma_f32_32x32x16_bf16 (K = 27 padded to 32) instead of 14 v_mfma_f32_32x32x2_f32 -- 192
+    // instead of 896 matrix-pipe cycles per 32 x 32 block.  The result is rounded to bf16 into the patch as before.
+    // K slots (group g = 2 s + h of MFMA step s, lane half h; 8 slots j each), k = 9 u + i = float offset 105 u + i in the patch:
+    //   g0: k = j              g1: k = 9 + j              g2: k = 18 + j              g3: j = 0, 1, 2 -> k = 8, 17, 26; else zero weight
+    bf16x8 bh[2], bl[2];
 #pragma unroll
-    for (int s = 0; s < 14; ++s) b0[s] = p.w0[(fh ? k_of_step(s, 1) : k_of_step(s, 0)) * C0 + fr];
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = s == 0 ? j : 18 + j;                                  // lane half 0
+            const int k1 = s == 0 ? 9 + j : (j < 3 ? 8 + 9 * j : -1);            // lane half 1
+            const float w0v = p.w0[k0 * C0 + fr];
+            const float w1v = k1 >= 0 ? p.w0[k1 * C0 + fr] : 0.0f;
+            const float wv = fh ? w1v : w0v;
+            const __bf16 hi = (__bf16)wv;
+            bh[s][j] = hi;
+            bl[s][j] = (__bf16)(wv - (float)hi);
+        }
     const float sc0 = p.scale0[fr], sh0 = p.shift0[fr];
     const int wm = wave >> 1, wn = wave & 1;
     const float sc1 = p.scale1[wn * 32 + fr], sh1 = p.shift1[wn * 32 + fr];
@@ -429,8 +446,40 @@ __global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
     constexpr int OUT2_OFF = 128 * 128;      // second staging tile, behind the first (both inside the dead patch region)
     static_assert(OUT2_OFF + 128 * 64 <= PATCH_B, "staging tiles must fit the patch region");
 
-    const int a1lo = PATCH_B + W1_B + (2 * wave * IW * 3 + fr * 3 + 105 * fh) * 4;
-    const int a1hi = PATCH_B + W1_B + (2 * wave * IW * 3 + fr * 3 + 210 + 5 * fh) * 4;
+    // A operand of a conv0 block: 16 floats of the image patch per lane, relative to the pixel's patch origin o (bytes):
+    //   step 0: o + (105 h + j) 4;   step 1, h = 0: o + (210 + j) 4;   h = 1: j = 0, 1, 2 -> o + (8 + 105 j) 4, j >= 3 -> anything finite
+    // (zero weight; o + (8 + j) 4 is taken).  Four per-lane displacements + immediates cover all 16 reads.
+    const int d0 = 420 * fh, d1 = fh ? 32 : 840, d2 = fh ? 452 - 4 : 840, d3 = fh ? 872 - 8 : 840;
+    const int a1o = PATCH_B + W1_B + (2 * wave * IW * 3 + fr * 3) * 4;      // origin of pixel (y = 2 wave, x = fr)
+    auto conv0_block = [&](int o) -> f32x16 {
+        float xs[16];
+        const int v0 = o + d0, v1 = o + d1, v2 = o + d2, v3 = o + d3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[j] = *reinterpret_cast<const float *>(lds + v0 + j * 4);
+        xs[8] = *reinterpret_cast<const float *>(lds + v1);
+        xs[9] = *reinterpret_cast<const float *>(lds + v2 + 4);
+        xs[10] = *reinterpret_cast<const float *>(lds + v3 + 8);
+#pragma unroll
+        for (int j = 3; j < 8; ++j) xs[8 + j] = *reinterpret_cast<const float *>(lds + v1 + j * 4);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            bf16x8 ah, al;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = xs[8 * s_ + j];
+                const __bf16 hi = (__bf16)xv;
+                ah[j] = hi;
+                al[j] = (__bf16)(xv - (float)hi);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s_], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s_], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s_], acc, 0, 0, 0);
+        }
+        return acc;
+    };
     // phase 1 write: element e -> pixel x = xe + 4 fh of row y; channel n = fr: chunk (n >> 3) ^ (((xe >> 2) + fh) & 3)
     int xr[4];
 #pragma unroll
@@ -497,15 +546,7 @@ __global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
         // ---- phase 1: conv0 (fp32 MFMA) -> bf16 patch ----
         auto conv0_row = [&](auto ytag) {
             constexpr int YD = decltype(ytag)::value;
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-            float a[14];
-#pragma unroll
-            for (int s = 0; s < 14; ++s)
-                a[s] = *reinterpret_cast<const float *>(lds + (s < 9 ? a1lo + s * 4 : a1hi + (s - 9) * 4) + YD * IW * 3 * 4);
-#pragma unroll
-            for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc, 0, 0, 0);
+            const f32x16 acc = conv0_block(a1o + YD * IW * 3 * 4);
             const int y = 2 * wave + YD;
             const bool zrow = (ty == 0) && (y == 0);
             const int base = (y * PW + 2 * fh) * 64;
@@ -530,17 +571,8 @@ __global__ __launch_bounds__(stem::NT, 4) void conv_stem_bf16(const StemArgs p)
         conv0_row(I1{});
         if (wave == 0) conv0_row(I16{});
         if (wave == 1) {   // column x = 32: lane row = patch row y
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
             const int yl = fr < PH ? fr : PH - 1;
-            const int abase = PATCH_B + W1_B + ((yl * IW + 32) * 3) * 4;
-            float a[14];
-#pragma unroll
-            for (int s = 0; s < 14; ++s)
-                a[s] = *reinterpret_cast<const float *>(lds + abase + (s < 9 ? (105 * fh + s) * 4 : (210 + 5 * fh + s - 9) * 4));
-#pragma unroll
-            for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc, 0, 0, 0);
+            const f32x16 acc = conv0_block(PATCH_B + W1_B + ((yl * IW + 32) * 3) * 4);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int y = (e & 3) + 8 * (e >> 2) + 4 * fh;
