@@ -103,10 +103,10 @@ def test_tile_built_reports_the_default_tile_set():
     assert not _lib.tile_built(7, 0)
     assert x3 == list(_lib.TILES_X3_BUILT)
     if exp:
-        assert f32 == list(range(len(_lib.TILES))) and bf16 == list(range(30))
+        assert f32 == list(range(len(_lib.TILES))) and bf16 == list(range(len(_lib.TILES_BF16)))
         assert x2 == sorted(_lib.TILES_X2_BUILT + _lib.PROBE_TILES_X2)
     else:
-        assert f32 == list(range(20)) + [23, 24] + list(range(26, 33)) and bf16 == list(range(20)) + list(range(21, 30))
+        assert f32 == list(range(20)) + [23, 24] + list(range(26, 33)) and bf16 == list(range(20)) + list(range(21, len(_lib.TILES_BF16)))
         assert x2 == list(_lib.TILES_X2_BUILT)
     # every tile a committed tuning table names is in the default set
     import glob

@@ -571,7 +571,7 @@ def test_bf16_pipelined_tile_repeatable_and_matches_oracle(rt):
         assert all(torch.equal(a, b) for a, b in zip(first, again))
 
 
-@pytest.mark.parametrize("tile", range(30))
+@pytest.mark.parametrize("tile", range(32))
 def test_bf16_every_tile(rt, tile):
     _need_tile("bf16", tile)
     from tests.helpers import mini_program

@@ -64,7 +64,8 @@ TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4
               (256, 256, 8, 64),  # 20: pipelined K loop (prefetch in flight across raw barriers, counted vmcnt)
               (128, 256, 8, 32), (256, 128, 8, 32), (128, 128, 4, 32),  # 21..23: LDS-DMA, BK 32: several workgroups per CU
               (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64),  # 24..26: tiles 17..19 on 16x16x32 MFMAs
-              (128, 128, 4, 64), (128, 64, 4, 64), (64, 128, 4, 64)]       # 27..29: tiles 8, 10, 12 on 16x16x32 MFMAs
+              (128, 128, 4, 64), (128, 64, 4, 64), (64, 128, 4, 64),       # 27..29: tiles 8, 10, 12 on 16x16x32 MFMAs
+              (128, 64, 4, 32), (64, 64, 4, 32)]                          # 30, 31: LDS-DMA, BK 32, 64 output channels
 TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if (26 <= i <= 32 or 37 <= i <= 40 or i in (42, 43, 45)) else "")
               + ("sk" if 33 <= i <= 40 else "") + ("rp" if i >= 41 else "")
               for i, (bm, bn, w, st) in enumerate(TILES)]

@@ -670,6 +670,7 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {256, 256, 8, 64},                                            // 20: pipelined K loop (counted vmcnt, raw barriers)
     {128, 256, 8, 32}, {256, 128, 8, 32}, {128, 128, 4, 32},      // 21..23: LDS-DMA with BK = 32, several workgroups per CU
     {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64}, {128, 128, 4, 64}, {128, 64, 4, 64}, {64, 128, 4, 64},  // 24..29: 16x16x32 MFMAs
+    {128, 64, 4, 32}, {64, 64, 4, 32},                            // 30, 31: LDS-DMA with BK = 32 for the Cin = 32 / Cout = 64 layer
 };
 
 TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < BF16_TILE_COUNT) ? tile : 0]; }
@@ -752,6 +753,8 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
         case 27: return launch_tb<2, 2, 2, 2, 64, true, 1, true>(a, out_f32, s);   // tile 8 (128x128, 4 waves) on 16x16x32
         case 28: return launch_tb<2, 1, 2, 2, 64, true, 1, true>(a, out_f32, s);   // tile 10 (128x64, 4 waves) on 16x16x32
         case 29: return launch_tb<1, 2, 2, 2, 64, true, 1, true>(a, out_f32, s);   // tile 12 (64x128, 4 waves) on 16x16x32
+        case 30: return launch_tb<2, 1, 2, 2, 32, true>(a, out_f32, s);      // 128x64, 4 waves, BK 32, LDS-DMA (tile 5 without the VGPR round trip)
+        case 31: return launch_tb<1, 1, 2, 2, 32, true>(a, out_f32, s);      // 64x64, 4 waves, BK 32, LDS-DMA
         default: return hipErrorInvalidValue;
     }
 }

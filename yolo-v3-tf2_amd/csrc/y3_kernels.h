@@ -97,7 +97,7 @@ hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s);
 hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s);   // conv0 in fp32 arithmetic, bf16 patch, conv1 on bf16 MFMA
 
 // bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
-static constexpr int BF16_TILE_COUNT = 30;
+static constexpr int BF16_TILE_COUNT = 32;
 TileInfo conv_bf16_tile_info(int tile);
 bool conv_bf16_tile_built(int tile);
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);
