@@ -158,6 +158,9 @@ def main():
                     help="all-gather of the packed detections: y3 = y3_allgather_results (RCCL behind the C ABI, one group on "
                          "the compute stream, graph-capturable); torch = torch.distributed.all_gather_into_tensor (RCCL)")
     ap.add_argument("--per-layer", action="store_true", help="also print the per-conv timing table to stderr")
+    ap.add_argument("--no-sclk", action="store_true",
+                    help="skip the in-kernel clock measurement (~1 s of extra forwards after the timed region): profiler runs "
+                         "(tools/profile.sh) use it so that every conv launch of the run belongs to a counted step")
     args = ap.parse_args()
 
     # host threads for the CPU legs (oracle parity gate, cpu_baseline): this process's real CPU share, fixed before any
@@ -307,7 +310,9 @@ def main():
     # shader clock under this load, measured in-kernel after the timed region (sysfs / rocm-smi report the DPM level, not
     # the clock the chip holds at its power cap): ~1 s of forwards back to back, the last one's stem kernel is stamped
     sclk_mhz, sclk_src = None, None
-    if rank == 0:
+    if rank == 0 and args.no_sclk:
+        sclk_src = "not measured (--no-sclk)"
+    elif rank == 0:
         try:
             fw = max(10, int(1000.0 / max(1.0, dt / args.steps * 1e3)))
             mhz, t_start, t_end = net.measure_sclk_all(images, grids, forwards=fw)

@@ -19,10 +19,11 @@ def short(name):
         dma = ",dma" if m.group(9) in ("true", "1") else ""
         sk = ",streamk" if m.group(10) == "1" else ""
         return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{m.group(6)}{dma}{sk}{',cat' if m.group(5) == 'true' else ''}>"
-    m = re.search(r"conv_bf16_mfma<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)", name)
+    m = re.search(r"conv_bf16_mfma<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(?:, (true|false), (\d+), (true|false))?", name)
     if m:
         tm, tn, wr, wc, bk = (int(m.group(i)) for i in range(1, 6))
-        return (f"conv_bf16_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},k{bk}{',cat' if m.group(6) == 'true' else ''}"
+        return (f"conv_bf16_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},k{bk}{',dma' if m.group(8) == 'true' else ''}"
+                f"{',16x16x32' if m.group(10) == 'true' else ''}{',cat' if m.group(6) == 'true' else ''}"
                 f"{',f32out' if m.group(7) == 'true' else ''}>")
     m = re.search(r"conv_f32x3_mfma<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)", name)
     if m:
