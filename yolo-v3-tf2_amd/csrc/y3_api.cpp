@@ -1173,12 +1173,31 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
     // equal sub-batches (measured with tools/lanes_sweep.py: weighted 2:3 / 3:4:5 splits were 2-3 % slower)
     int start[Y3_MAX_LANES + 1];
     for (int l = 0; l <= lanes; ++l) start[l] = (int)((long long)batch * l / lanes);
+    for (int l = 0; l < lanes; ++l)
+        if (start[l + 1] > start[l]) HIP_TRY(hipStreamWaitEvent(net->lane_stream[l], net->fork_ev, 0));
+    if (k_early > 0) {
+        for (int l = 0; l < lanes; ++l) {
+            const int nb = start[l + 1] - start[l];
+            if (nb <= 0) continue;
+            y3_status st = run_lane(start[l], nb, net->lane_stream[l], l, lanes);
+            if (st != Y3_OK) return st;
+        }
+    } else {
+        // op-major enqueue: op k of every lane before op k+1 of any.  Enqueued lane by lane, an eager forward gives lane 0 a
+        // head start of one whole forward's worth of host launch time (0.3 ms; 0.9 ms under a profiler: the per-queue timeline of
+        // tools/timeline_dump.py shows lane 0 four kernels ahead), and a start offset between the lanes only costs
+        // (profiles/r03_ab_lane_stagger.txt).  A captured forward replays with both branches released at once either way.
+        const int n_ops = (int)net->ops.size();
+        for (int oi = 0; oi < n_ops; ++oi)
+            for (int l = 0; l < lanes; ++l) {
+                const int nb = start[l + 1] - start[l];
+                if (nb <= 0) continue;
+                y3_status st = run_slice(net, images, grids, start[l], nb, net->lane_stream[l], nullptr, 0, l, lanes, oi, oi + 1);
+                if (st != Y3_OK) return st;
+            }
+    }
     for (int l = 0; l < lanes; ++l) {
-        const int nb = start[l + 1] - start[l];
-        if (nb <= 0) continue;
-        HIP_TRY(hipStreamWaitEvent(net->lane_stream[l], net->fork_ev, 0));
-        y3_status st = run_lane(start[l], nb, net->lane_stream[l], l, lanes);
-        if (st != Y3_OK) return st;
+        if (start[l + 1] <= start[l]) continue;
         HIP_TRY(hipEventRecord(net->join_ev[l], net->lane_stream[l]));
         HIP_TRY(hipStreamWaitEvent(s, net->join_ev[l], 0));
     }
