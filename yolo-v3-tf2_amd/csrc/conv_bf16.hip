@@ -40,9 +40,27 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 // Same LDS image, same bytes read per K tile, same MFMA cycles per FLOP; the chip holds a higher clock on this shape
 // (MI355X_MICROARCH.md "DVFS give-back" item 7: 1.12-1.15 x the FLOP/s on random data).  Fragment: lane l holds k = 8 (l >> 4) ..
 // + 7 of row l & 15; C: acc[mb][nb][j] = row 16 mb + 4 (l >> 4) + j, column 16 nb + (l & 15).
+#ifdef Y3_PHASE_STAMPS
+// Diagnostic build only (csrc/build.py --variant ... -DY3_PHASE_STAMPS, tools/phase_stamps.py): thread 0 of every workgroup of the
+// launches whose K equals y3_dbg_sel_k stores s_memrealtime (100 MHz) at kernel entry, before the first fetch, after the first
+// barrier, after the K loop and after the epilogue, plus HW_ID / XCC_ID, into a buffer no other code reads.
+__device__ unsigned long long y3_dbg_stamps[8 * 8192];
+__device__ int y3_dbg_sel_k = -1;
+#define Y3_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && p.K == y3_dbg_sel_k) y3_dbg_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define Y3_STAMP(k) do { } while (0)
+#endif
+
 template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false, int MINW = 1, bool M16 = false>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvArgs p)
 {
+    Y3_STAMP(0);
+#ifdef Y3_PHASE_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 8192 && p.K == y3_dbg_sel_k) {
+        y3_dbg_stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        y3_dbg_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    }
+#endif
     static_assert(!DMA || BK == 64 || BK == 32, "LDS-DMA variant needs 128-byte or 64-byte rows");
     static_assert(!M16 || (DMA && BK == 64), "the 16x16x32 form is built on the 128-byte swizzled rows");
     constexpr int MB = M16 ? 2 * TM : TM, NB = M16 ? 2 * TN : TN;   // accumulator blocks per wave
@@ -210,6 +228,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
             for (int e = 0; e < (M16 ? 4 : 16); ++e) acc[i][j][e] = 0.0f;
 
     const int KT = p.K / BK;
+    Y3_STAMP(1);
     if (DMA) {
         fetch_dma(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -218,6 +237,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
         stage(0);
     }
     __syncthreads();
+    Y3_STAMP(2);
 
     const int fr = M16 ? (lane & 15) : (lane & 31), fh = M16 ? (lane >> 4) : (lane >> 5);   // row in the block, k group
     const int a_frag = (wr * 32 * TM + fr) * ROWB + (DMA ? 0 : fh * 16);
@@ -260,6 +280,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
         __syncthreads();
     }
 
+    Y3_STAMP(3);
     // ---- epilogue through LDS, one 32-row sub-tile of every wave per pass ----------------------------------
     // pass i: wave (wr, wc) writes rows [wr*32, +32) x cols [wc*32*TN, +32*TN) of a [WR*32][BN+4] fp32 tile (its i-th
     // accumulator row block), then all threads convert 8 consecutive channels each and store 16 B.
@@ -352,6 +373,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
                 if (mw + r < p.M) *reinterpret_cast<u32x4 *>(dstb + (size_t)(mw + r) * p.Cout + nw + pc * 8) = out;
             }
         }
+        Y3_STAMP(4);   // thread 0 = wave 0: its own stores issued (not yet retired)
     } else {
         // ---- fp32 output (head grids, Cout = 255): workgroup-wide fp32 tile, one 32-row block of every wave per pass ----
         constexpr int EROWS = WR * 32;
@@ -672,6 +694,14 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64}, {128, 128, 4, 64}, {128, 64, 4, 64}, {64, 128, 4, 64},  // 24..29: 16x16x32 MFMAs
     {128, 64, 4, 32}, {64, 64, 4, 32},                            // 30, 31: LDS-DMA with BK = 32 for the Cin = 32 / Cout = 64 layer
 };
+
+#ifdef Y3_PHASE_STAMPS
+extern "C" int y3_dbg_select_k(int K) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(y3_dbg_sel_k), &K, sizeof(int)); }
+extern "C" int y3_dbg_copy_stamps(unsigned long long *dst, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(y3_dbg_stamps), (size_t)n_words * sizeof(unsigned long long));
+}
+#endif
 
 TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < BF16_TILE_COUNT) ? tile : 0]; }
 
