@@ -50,6 +50,32 @@ def main(out):
                 o.write(f"{short(r['Name']):<52s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} "
                         f"{float(r['AverageNs'])/1e3:10.2f} {float(r['MinNs'])/1e3:10.2f} {float(r['MaxNs'])/1e3:10.2f} "
                         f"{float(r['Percentage']):6.2f}\n")
+    # conv kernels on the wall clock: with sub-batch lanes the launches of different lanes overlap, so the summed durations above
+    # exceed the elapsed time -- report both per step (steps = NMS launches; the steps after the first two, warm-up excluded)
+    for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
+        rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
+        rows.sort()
+        marks = [e for s_, e, n in rows if "nms_kernel" in n]
+        if len(marks) >= 4:
+            t0, t1, nsteps = marks[1], marks[-1], len(marks) - 2
+            conv = [(s_, e) for s_, e, n in rows if "conv_" in n and s_ >= t0 and e <= t1]
+            total = sum(e - s_ for s_, e in conv)
+            union, cur_s, cur_e = 0, None, None
+            for s_, e in conv:
+                if cur_e is None or s_ > cur_e:
+                    if cur_e is not None:
+                        union += cur_e - cur_s
+                    cur_s, cur_e = s_, e
+                else:
+                    cur_e = max(cur_e, e)
+            if cur_e is not None:
+                union += cur_e - cur_s
+            with open(os.path.join(out, "summary_kernel_stats.txt"), "a") as o:
+                o.write(f"# conv kernels over the last {nsteps} steps of the traced run: summed durations {total / 1e6 / nsteps:.3f} ms per step, "
+                        f"time with at least one conv kernel running {union / 1e6 / nsteps:.3f} ms per step, "
+                        f"{len(conv) / nsteps:.1f} launches per step (sub-batch lanes overlap: the second figure is the one to hold against "
+                        f"bench.py's conv-stack time)\n")
+        break
     # PMC passes: sum counters per kernel name
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(int)
