@@ -188,12 +188,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     require_gpu()
-    torch.cuda.set_device(local_rank)
+    # Y3_BENCH_REHEARSE_GLOO=1: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (tools/visits:
+    # two ranks on the build box's one GPU) -- ranks share devices, the process group is gloo and the gather goes through host
+    # copies.  It checks sharding, the rank-order gate, the barriers and the max-over-ranks timing; it is NOT a measurement (the
+    # line says so in config.collective) and RCCL itself needs one GPU per rank.
+    rehearse = os.environ.get("Y3_BENCH_REHEARSE_GLOO") == "1"
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if rehearse else local_rank)
     use_dist = world > 1 or os.environ.get("Y3_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     B, S, nc, M = args.batch, args.image_size, 80, 100
     scaling = "weak"
     if args.global_batch > 0:
@@ -224,7 +232,9 @@ def main():
         gathered = (torch.empty((world * B, M, 7), dtype=torch.int32, device="cuda"),
                     torch.empty((world * B,), dtype=torch.int32, device="cuda"))
         collective = "torch.distributed.all_gather_into_tensor (RCCL)"
-        if args.collective == "y3":
+        if rehearse:
+            collective = "REHEARSAL: gloo all-gather of host copies, ranks sharing GPUs -- control flow only, not a measurement"
+        if args.collective == "y3" and not rehearse:
             try:
                 comm = Y3Comm.from_torch_distributed()
                 collective = "y3_allgather_results (RCCL group behind the C ABI, on the compute stream)"
@@ -239,13 +249,21 @@ def main():
                 comm = None
                 collective = "torch.distributed.all_gather_into_tensor (RCCL) -- y3_comm init failed on another rank"
 
+    def gather_torch(packed, nv):
+        if not rehearse:
+            return allgather_detections(packed, nv, out=gathered)   # torch.distributed (RCCL) when world > 1
+        hp, hn = allgather_detections(packed.cpu(), nv.cpu())        # gloo on host copies
+        gathered[0].copy_(hp)
+        gathered[1].copy_(hn)
+        return gathered
+
     if use_dist:
         # fail loud and early: one untimed gather of rank-stamped rows through the very route the timed loop uses; every
         # rank checks that block r of the result carries r (a communicator that mixes ranks up, or a route that silently
         # returns the local rows, stops the run here instead of producing a number)
         stamp = (torch.full((B, M, 7), rank, dtype=torch.int32, device="cuda"),
                  torch.full((B,), rank, dtype=torch.int32, device="cuda"))
-        got = comm.allgather(*stamp, out=gathered) if comm is not None else allgather_detections(*stamp, out=gathered)
+        got = comm.allgather(*stamp, out=gathered) if comm is not None else gather_torch(*stamp)
         torch.cuda.synchronize()
         want = torch.arange(world, dtype=torch.int32, device="cuda").repeat_interleave(B)
         if not (torch.equal(got[1], want) and torch.equal(got[0][:, 0, 6], want) and torch.equal(got[0][:, M - 1, 0], want)):
@@ -267,7 +285,9 @@ def main():
         last["tuple"] = (bboxes, cls, scores, sel, nv)
         if comm is not None:
             return comm.allgather(packed, nv, out=gathered)     # one RCCL group enqueued by liby3hip.so
-        return allgather_detections(packed, nv, out=gathered)   # torch.distributed (RCCL) when world > 1
+        if use_dist:
+            return gather_torch(packed, nv)
+        return allgather_detections(packed, nv, out=gathered)   # single process: returns its inputs
 
     def fence():
         if use_dist:
