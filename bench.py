@@ -73,6 +73,40 @@ def parity_gate(program, weights, anchors, images_host, device_out, n, M, iou, s
     return out
 
 
+def parity_gate_bf16(program, weights, images_host, grids, n):
+    """bf16 plans (BASELINE config 5): the head logits of the first n images of the batch against the bf16-emulating oracle
+    (rounds to bf16 exactly where the pipeline stores).  Two bf16 pipelines that differ only in the order of their fp32 partial
+    sums decorrelate to ~1 ulp rms within ~10 layers (tests/test_oracle.py::test_bf16_free_running_floor), so the bar is that
+    floor, measured here on these very images: the oracle against itself with fp64 partial sums.  The kernels must be no further
+    from the oracle than twice (relative L2) / three times (max) the oracle is from itself; the distance to the fp32 oracle (what
+    bf16 costs) is reported and bounded.  The per-layer one-ulp bar on identical inputs is a test
+    (test_bf16_every_layer_teacher_forced_within_one_ulp), not a bench step.  Raises on failure."""
+    import numpy as np
+    from oracle import oracle as O
+    x = images_host[:n]
+    got = [g[:n].cpu().numpy().reshape(n, g.shape[1], g.shape[2], -1) for g in grids]
+    ref16 = O.forward(program, weights, x, bf16=True)
+    ref16b = O.forward(program, weights, x, bf16=True, acc64=True)
+    ref32 = O.forward(program, weights, x)
+    rel = lambda a, b: float(np.linalg.norm(a.reshape(-1) - b.reshape(-1)) / np.linalg.norm(b.reshape(-1)))   # noqa: E731
+    mx = lambda a, b: float(np.abs(a.reshape(-1) - b.reshape(-1)).max())                                      # noqa: E731
+    floor_rel = max(rel(a, b) for a, b in zip(ref16b, ref16))
+    floor_max = max(mx(a, b) for a, b in zip(ref16b, ref16))
+    rel16 = max(rel(g, r) for g, r in zip(got, ref16))
+    d16 = max(mx(g, r) for g, r in zip(got, ref16))
+    rel32 = max(rel(g, r) for g, r in zip(got, ref32))
+    d32 = max(mx(g, r) for g, r in zip(got, ref32))
+    out = {"images": n, "what": "head logits (three grids) vs oracle.forward(bf16=True)",
+           "rel_l2_vs_bf16_oracle": rel16, "max_abs_vs_bf16_oracle": d16,
+           "floor_rel_l2_oracle_vs_oracle": floor_rel, "floor_max_abs_oracle_vs_oracle": floor_max,
+           "rel_l2_vs_fp32_oracle": rel32, "max_abs_vs_fp32_oracle": d32,
+           "bar": "rel <= 2 x floor and max <= 3 x floor (two bf16 pipelines with different summation orders decorrelate to ~1 ulp rms); "
+                  "vs fp32: rel < 3e-2"}
+    if not (rel16 <= 2.0 * floor_rel and d16 <= 3.0 * floor_max and rel32 < 3e-2):
+        raise SystemExit(f"PARITY GATE FAILED (bf16): {out} -- no number reported")
+    return out
+
+
 def host_cpu_share():
     """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands one GPU's
     share of a 256-thread host to the job; running 256 threads on it thrashes)."""
@@ -302,6 +336,9 @@ def main():
     if rank == 0 and args.parity_images > 0 and args.dtype != "bf16":
         torch.cuda.synchronize()
         parity = parity_gate(program, weights, anchors, images_host, last["tuple"], min(args.parity_images, B), M, 0.5, 0.1)
+    elif rank == 0 and args.parity_images > 0:
+        torch.cuda.synchronize()
+        parity = parity_gate_bf16(program, weights, images_host, grids, min(args.parity_images, B, 1))   # one image: three oracle passes
     if use_dist:
         dist.barrier()
     for _ in range(2):      # the gate left the GPU idle for seconds: bring clocks and caches back before the timed region
