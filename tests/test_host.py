@@ -135,3 +135,27 @@ def test_bench_host_helpers(monkeypatch):
     monkeypatch.setenv("Y3_CPU_THREADS", "1")
     assert bench.host_cpu_share() == 1
 
+
+
+def test_bench_bf16_parity_gate_passes_the_floor_and_rejects_garbage(program, weights):
+    """bench.py's bf16 gate on the CPU: fed the oracle's own bf16 forward with the other summation order (which IS the floor the
+    gate measures) it passes with rel == floor; fed zeros, or logits with 5 % noise, it stops the run."""
+    import importlib.util
+    import os
+    import torch
+    from oracle import oracle as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("y3_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    x = bench.host_images(1, 64, 0)
+    alt = [torch.from_numpy(np.ascontiguousarray(g)) for g in O.forward(program, weights, x, bf16=True, acc64=True)]
+    out = bench.parity_gate_bf16(program, weights, x, alt, 1)
+    assert out["images"] == 1 and abs(out["rel_l2_vs_bf16_oracle"] - out["floor_rel_l2_oracle_vs_oracle"]) < 1e-12
+    assert 1e-3 < out["floor_rel_l2_oracle_vs_oracle"] < 2e-2 and out["rel_l2_vs_fp32_oracle"] < 3e-2
+    with pytest.raises(SystemExit, match="PARITY GATE FAILED"):
+        bench.parity_gate_bf16(program, weights, x, [torch.zeros_like(g) for g in alt], 1)
+    rng = np.random.default_rng(0)
+    noisy = [g * torch.from_numpy((1.0 + 0.05 * rng.standard_normal(tuple(g.shape))).astype(np.float32)) for g in alt]
+    with pytest.raises(SystemExit, match="PARITY GATE FAILED"):
+        bench.parity_gate_bf16(program, weights, x, noisy, 1)
