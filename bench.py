@@ -257,6 +257,7 @@ def main():
     net.plan(B, S, dt_ids[args.dtype])
     if args.lanes > 0:
         net.set_lanes(args.lanes)
+    headline_lanes = int(getattr(net, "lanes", 1))     # the alt measurements below re-plan the net with their own tables
     images_host = host_images(B, S, rank)
     images = torch.from_numpy(images_host).cuda()      # resident in HBM before the timed region starts
     grids = [torch.empty((B, g, g, 3, 5 + nc), device="cuda") for g in net.grid_sizes()]
@@ -475,11 +476,12 @@ def main():
                                    + (", RCCL all-gather" if use_dist else ""),
                        "collective": collective, "rccl_ranks": world if use_dist else 0,
                        "rank_order_checked": bool(use_dist), "hip_graph": graph is not None,
+                       "lanes": headline_lanes,   # concurrent sub-batches per forward (tuning table / --lanes)
                        "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
                        "mean_num_valid": round(nv_mean, 2)},
             "roofline": {
-                "bound": "mfma", "kernel": ("conv stack (fused stem kernel = conv0..2 in one launch + 72 x conv_f32_mfma launches per step)" if args.dtype == "f32"
-                                            else "conv stack (fused stem kernel = conv0..1 in one launch + 73 x conv_bf16_mfma launches per step)" if args.dtype == "bf16"
+                "bound": "mfma", "kernel": ("conv stack (fused stem kernel = conv0..2 in one launch + 72 x conv_f32_mfma launches per step and lane)" if args.dtype == "f32"
+                                            else "conv stack (fused stem kernel = conv0..2 in one launch + 72 x conv_bf16_mfma launches per step and lane)" if args.dtype == "bf16"
                                             else f"conv stack (74 x conv_f32x3_mfma{'<2 planes>' if args.dtype == 'f32x2' else ''} launches + 1 first-layer conv per step)"),
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved * mfma_flops_factor / peak, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -100,6 +100,7 @@ class Net:
 
     def set_lanes(self, lanes: int):
         check(self.lib.y3_net_set_lanes(self._h, int(lanes)), "y3_net_set_lanes")
+        self.lanes = int(lanes)
 
     def set_xcd_mode(self, mode: int):
         """fp32 conv tile placement on the 8 XCDs: 1 = XCD-blocked order chosen per conv (default), 0 = contiguous runs."""
