@@ -30,9 +30,13 @@ def main():
     ap.add_argument("--tile", type=int, default=24)
     ap.add_argument("--shortcut", type=int, default=1)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--size", type=int, default=3, help="3: 3x3 conv cin -> cout (the block's second conv); 1: time the block's 1x1 conv cout -> cin instead")
     a = ap.parse_args()
     lib = C.CDLL(_lib.LIB_PATH)
-    if not hasattr(lib, "y3_dbg_select_k"):
+    f32 = a.dtype == "f32"
+    sel, cpy, cap = ("y3_dbg32_select_k", "y3_dbg32_copy_stamps", 32768) if f32 else ("y3_dbg_select_k", "y3_dbg_copy_stamps", 8192)
+    if not hasattr(lib, sel):
         sys.exit("this library has no phase stamps: build the -DY3_PHASE_STAMPS variant and set Y3_LIB_PATH")
     # residual block: 1x1 cout -> cin, then the 3x3 cin -> cout under test with the block input as shortcut
     chain = [dict(filters=a.cin, size=1), dict(filters=a.cout, size=3, shortcut=-3 if a.shortcut else 0)]
@@ -41,26 +45,33 @@ def main():
     p = mini_program(a.cout, chain, [dict(filters=64, size=1), dict(filters=64, size=1), dict(filters=64, size=1)])
     net = runtime.Net(p)
     net.load_weights(synthetic_weights(p, seed=1))
-    net.set_tile_bf16(1, a.tile)
-    net.plan(a.batch, a.s, _lib.Y3_DTYPE_BF16)
+    slot = 1 if a.size == 3 else 0
+    if a.tile >= 0:
+        (net.set_tile if f32 else net.set_tile_bf16)(slot, a.tile)
+    net.plan(a.batch, a.s, _lib.Y3_DTYPE_F32 if f32 else _lib.Y3_DTYPE_BF16)
     net.set_lanes(1)
-    x = torch.randn((a.batch, a.s, a.s, a.cout), device="cuda").to(torch.bfloat16)
-    K = 9 * a.cin
-    assert lib.y3_dbg_select_k(C.c_int(K)) == 0
+    x = torch.randn((a.batch, a.s, a.s, a.cout), device="cuda")
+    if not f32:
+        x = x.to(torch.bfloat16)
+    K = 9 * a.cin if a.size == 3 else a.cout
+    assert getattr(lib, sel)(C.c_int(K)) == 0
     for _ in range(a.reps):
         net.forward(x)
     torch.cuda.synchronize()
-    bm, bn = _lib.TILES_BF16[a.tile][0], _lib.TILES_BF16[a.tile][1]
-    M = a.batch * a.s * a.s
-    nwg = ((M + bm - 1) // bm) * (a.cout // bn)
-    n = min(nwg, 8192)
-    buf = (C.c_ulonglong * (8 * 8192))()
-    assert lib.y3_dbg_copy_stamps(buf, C.c_int(8 * 8192)) == 0
-    st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8)[:n].astype(np.int64)
+    buf = (C.c_ulonglong * (8 * cap))()
+    assert getattr(lib, cpy)(buf, C.c_int(8 * cap)) == 0
+    st_all = np.frombuffer(buf, dtype=np.uint64).reshape(cap, 8).astype(np.int64)
+    n = int((st_all[:, 0] > 0).sum())                 # stamped workgroups (blockIdx order: a prefix)
+    nwg = n
+    st = st_all[:n]
+    bm = bn = 0
+    if a.tile >= 0:
+        bm, bn = (_lib.TILES if f32 else _lib.TILES_BF16)[a.tile][0], (_lib.TILES if f32 else _lib.TILES_BF16)[a.tile][1]
     t = st[:, :5] * 10.0 / 1000.0          # us (100 MHz ticks)
     t0 = t[:, 0].min()
     names = ["entry -> addresses ready", "first fetch + barrier", "K loop", "epilogue (to this wave's last store issue)"]
-    print(f"{nwg} workgroups ({n} stamped), tile {bm}x{bn}, K = {K}, launch span {t[:, 4].max() - t0:.1f} us")
+    print(f"{a.dtype}: {n} stamped workgroups" + (" (buffer full)" if n == cap else "") + f", tile {bm}x{bn} (0x0: the plan's choice), K = {K}, "
+          f"launch span {t[:, 4].max() - t0:.1f} us")
     for k in range(4):
         d = t[:, k + 1] - t[:, k]
         print(f"  {names[k]:46s} median {np.median(d):7.2f} us   p10 {np.percentile(d, 10):7.2f}   p90 {np.percentile(d, 90):7.2f}")
@@ -81,7 +92,7 @@ def main():
             gaps.append(t[b_, 0] - t[a_, 4])
     gaps = np.array(gaps)
     print(f"  distinct CUs seen: {len(per_cu)}; workgroups per CU: {np.mean([len(v) for v in per_cu.values()]):.2f}")
-    if len(gaps):
+    if len(gaps) and not f32:      # fp32 tiles: several workgroups are resident per CU, consecutive ones overlap
         print(f"  {'gap on a CU: last stamp -> next entry':46s} median {np.median(gaps):7.2f} us   p10 {np.percentile(gaps, 10):7.2f}   p90 {np.percentile(gaps, 90):7.2f}")
     starts = np.sort(t[:, 0] - t0)
     print(f"  first-round entries spread over {starts[min(255, n - 1)]:.2f} us; last workgroup enters at {starts[-1]:.1f} us")

@@ -56,9 +56,27 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
 // cdna_hip_programming.md section 5 (split-K slab reducer) / Guideline 16.
 // RESPF != 0 (tiles 41..45, convs with a shortcut operand only): the residual values of the tile are requested at the
 // top of the LAST K iteration instead of after it, so their latency runs under that iteration's 32 MFMAs per wave.
+#ifdef Y3_PHASE_STAMPS
+// Diagnostic build only (csrc/build.py --variant ... -DY3_PHASE_STAMPS, tools/phase_stamps.py --dtype f32): thread 0 of every workgroup
+// (up to 32768) of the launches whose K equals y3_dbg32_sel_k stores s_memrealtime (100 MHz) at kernel entry, before the first fetch,
+// after the first barrier, after the K loop and after the epilogue, plus HW_ID / XCC_ID, into a buffer no other code reads.
+__device__ unsigned long long y3_dbg32_stamps[8 * 32768];
+__device__ int y3_dbg32_sel_k = -1;
+#define Y3_STAMP32(k) do { if (threadIdx.x == 0 && blockIdx.x < 32768 && p.K == y3_dbg32_sel_k) y3_dbg32_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define Y3_STAMP32(k) do { } while (0)
+#endif
+
 template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0, int RESPF = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvArgs p)
 {
+    Y3_STAMP32(0);
+#ifdef Y3_PHASE_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 32768 && p.K == y3_dbg32_sel_k) {
+        y3_dbg32_stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        y3_dbg32_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    }
+#endif
     static_assert(!(RESPF && SK), "residual prefetch is built for the classic schedule only");
     constexpr int LDS_ROW = DMA ? BK : BK + 4;  // floats per LDS row
     constexpr int BM = 32 * TM * WR;
@@ -234,9 +252,19 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
             unsigned mk = 0;
             if (ahw[i] >= 0 || (ahw[i] >> 16) != -32768) {
                 const int hi0 = ahw[i] >> 16, wi0 = (int)(short)(ahw[i] & 0xffff);
-                for (int u = 0; u < p.ksize; ++u)
-                    for (int v = 0; v < p.ksize; ++v)
-                        if ((unsigned)(hi0 + u) < (unsigned)p.H && (unsigned)(wi0 + v) < (unsigned)p.W) mk |= 1u << (u * p.ksize + v);
+                if (p.ksize == 3) {
+                    // closed form of the loop below: row u contributes bits 3u..3u+2, column v bit v of each row.  With the SIMD full
+                    // of 64-cycle MFMAs every vector instruction of a prologue waits ~one MFMA for its issue slot
+                    // (tools/phase_stamps.py --dtype f32: 32 us from entry to the first fetch): six compares instead of two nested loops
+                    const unsigned H = (unsigned)p.H, W = (unsigned)p.W;
+                    const unsigned rm = ((unsigned)hi0 < H ? 7u : 0u) | ((unsigned)(hi0 + 1) < H ? 56u : 0u) | ((unsigned)(hi0 + 2) < H ? 448u : 0u);
+                    const unsigned cm = ((unsigned)wi0 < W ? 1u : 0u) | ((unsigned)(wi0 + 1) < W ? 2u : 0u) | ((unsigned)(wi0 + 2) < W ? 4u : 0u);
+                    mk = rm & (cm * 73u);
+                } else {
+                    for (int u = 0; u < p.ksize; ++u)
+                        for (int v = 0; v < p.ksize; ++v)
+                            if ((unsigned)(hi0 + u) < (unsigned)p.H && (unsigned)(wi0 + v) < (unsigned)p.W) mk |= 1u << (u * p.ksize + v);
+                }
             }
             okmask[i] = mk;
             abase4[i] = (unsigned)(aoff[i] + lchunk) * 4u;
@@ -319,6 +347,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    Y3_STAMP32(1);
     if (DMA) {
         fetch_dma(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -327,6 +356,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         stage(0);
     }
     __syncthreads();
+    Y3_STAMP32(2);
 
     const int a_frag = (wr * 32 * TM + fr) * LDS_ROW + (DMA ? 0 : fh * 4);
     const int b_frag = BM * LDS_ROW + (wc * 32 * TN + fr) * LDS_ROW + (DMA ? 0 : fh * 4);
@@ -434,6 +464,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         }
     }
 
+    Y3_STAMP32(3);
     // ---- stream-K: a cut tile is completed by whoever contributes last -----------------------------------
     if (SK && (seg_k0 != 0 || seg_k1 != KT)) {
         constexpr unsigned SLAB = BM * BN * 4;                    // bytes of one partial tile: [TM*TN*4][NT] x 16 B
@@ -557,6 +588,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     } else {
         if (p.leaky) emit2(T_{}, F_{}); else emit2(F_{}, F_{});
     }
+    Y3_STAMP32(4);   // thread 0 = wave 0: its own stores issued (not yet retired)
   } while (SK && (it += seg_k1 - seg_k0, first_segment = false, it < it_end));
     if (p.clk_stamps != nullptr && blockIdx.x == (gridDim.x >> 1) && tid == 0) {
         p.clk_stamps[2] = __builtin_amdgcn_s_memtime();
@@ -581,6 +613,14 @@ static const TileInfo kTiles[TILE_COUNT] = {
     // 41..45: residual prefetch variants of tiles 10, 31, 27, 11, 26 (convs with a shortcut operand only)
     {64, 128, 4, 1}, {64, 128, 4, 1}, {64, 64, 4, 2}, {64, 64, 4, 1}, {64, 128, 4, 2},
 };
+
+#ifdef Y3_PHASE_STAMPS
+extern "C" int y3_dbg32_select_k(int K) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(y3_dbg32_sel_k), &K, sizeof(int)); }
+extern "C" int y3_dbg32_copy_stamps(unsigned long long *dst, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(y3_dbg32_stamps), (size_t)n_words * sizeof(unsigned long long));
+}
+#endif
 
 TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUNT) ? tile : 0]; }
 
