@@ -687,7 +687,9 @@ template <int TM, int TN, int WR, int WC, int MINW1 = 1>
 static hipError_t launch_t(const ConvArgs &a, int stages, hipStream_t s)
 {
     // MINW1: register budget (waves per SIMD) of the single-stage variant -- with 4, the two accumulators of the
-    // 32x64 wave tile stay in architectural VGPRs and the epilogue needs no v_accvgpr_read
+    // 32x64 wave tile stay in architectural VGPRs and the epilogue needs no v_accvgpr_read (nor the prologue 32-64
+    // v_accvgpr_write: with the SIMD full of 64-cycle MFMAs every vector instruction outside the K loop waits ~one MFMA for
+    // its issue slot, profiles/r03_ab_f32_prologue.txt).  The LDS-DMA tiles 26, 27, 31, 32 and the 64x64 tiles pass 4 as well.
     if (a.src1) return stages == 2 ? launch_k<TM, TN, WR, WC, true, 2>(a, s) : launch_k<TM, TN, WR, WC, true, 1, 0, MINW1>(a, s);
     return stages == 2 ? launch_k<TM, TN, WR, WC, false, 2>(a, s) : launch_k<TM, TN, WR, WC, false, 1, 0, MINW1>(a, s);
 }
@@ -702,7 +704,7 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 2: case 8: return launch_t<2, 1, 4, 1>(a, stages, s);    // 256x32
         case 3: case 9: return launch_t<1, 2, 4, 1, 4>(a, stages, s);    // 128x64
         case 4: case 10: return launch_t<1, 2, 2, 2, 4>(a, stages, s);   // 64x128
-        case 5: case 11: return launch_t<1, 1, 2, 2>(a, stages, s);   // 64x64
+        case 5: case 11: return launch_t<1, 1, 2, 2, 4>(a, stages, s);   // 64x64
         case 12: case 13: return launch_t<2, 1, 2, 4>(a, stages, s);  // 128x128, 8 waves
         case 14: case 15: return launch_t<1, 1, 4, 4>(a, stages, s);  // 128x128, 16 waves
         case 16: return launch_t<2, 1, 4, 4>(a, stages, s);           // 256x128, 16 waves
@@ -715,13 +717,13 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 25: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 4>(a, s);
 #endif
         // direct-to-LDS operand loads, double buffered
-        case 26: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 0, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 0, 1, 1>(a, s);  // 64x128
-        case 27: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 0, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 0, 1, 1>(a, s);  // 64x64
+        case 26: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 0, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 0, 4, 1>(a, s);  // 64x128
+        case 27: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 0, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 0, 4, 1>(a, s);  // 64x64
         case 28: return a.src1 ? launch_k<2, 2, 2, 2, true, 2, 0, 1, 1>(a, s) : launch_k<2, 2, 2, 2, false, 2, 0, 1, 1>(a, s);  // 128x128
         case 29: return a.src1 ? launch_k<1, 2, 4, 1, true, 2, 0, 1, 1>(a, s) : launch_k<1, 2, 4, 1, false, 2, 0, 1, 1>(a, s);  // 128x64
         case 30: return a.src1 ? launch_k<2, 1, 4, 1, true, 2, 0, 1, 1>(a, s) : launch_k<2, 1, 4, 1, false, 2, 0, 1, 1>(a, s);  // 256x32
-        case 31: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 1, 1>(a, s);  // 64x128, 1 stage
-        case 32: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 1>(a, s);  // 64x64, 1 stage
+        case 31: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 4, 1>(a, s);  // 64x128, 1 stage
+        case 32: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 4, 1>(a, s);  // 64x64, 1 stage
 #ifdef Y3_EXPERIMENTAL
         // stream-K schedule (33..40 = tiles 10, 11, 9, 17, 26, 27, 31, 32)
         case 33: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 4, 0, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 4, 0, 1>(a, s);
