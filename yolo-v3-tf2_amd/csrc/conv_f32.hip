@@ -562,16 +562,27 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                                                                   : __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)off[e], 0, 0));
                     }
                 }
+                // element pairs as 2-vectors: the compiler selects v_pk_add_f32 / v_pk_mul_f32 (one instruction per pair, the same
+                // IEEE operation per element): with the SIMD full of 64-cycle MFMAs every vector instruction of an epilogue
+                // waits ~one MFMA for its issue slot, so the count of instructions is what the epilogue costs
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = acc[i][j][e] + sh;
-                    if (LEAKY) v = fmaxf(v, 0.1f * v);   // == (v >= 0 ? v : 0.1 v) for every finite v
-                    if (RES) v = r[e] + v;
-                    const int so = ((e & 3) + 8 * (e >> 2)) * row_bytes;
-                    if (interior)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, (int)vbase, so, 0);
-                    else
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsd, (int)off[e], 0, 0);
+                for (int e = 0; e < 16; e += 2) {
+                    f32x2 v2 = f32x2{acc[i][j][e], acc[i][j][e + 1]} + f32x2{sh, sh};
+                    if (LEAKY) {
+                        const f32x2 t2 = v2 * f32x2{0.1f, 0.1f};
+                        v2 = f32x2{fmaxf(v2[0], t2[0]), fmaxf(v2[1], t2[1])};   // == (v >= 0 ? v : 0.1 v) for every finite v
+                    }
+                    if (RES) v2 = f32x2{r[e], r[e + 1]} + v2;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ee = e + h;
+                        const int so = ((ee & 3) + 8 * (ee >> 2)) * row_bytes;
+                        if (interior)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v2[h]), rsd, (int)vbase, so, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v2[h]), rsd, (int)off[ee], 0, 0);
+                    }
                 }
             }
         }
