@@ -92,6 +92,21 @@ def main():
             gaps.append(t[b_, 0] - t[a_, 4])
     gaps = np.array(gaps)
     print(f"  distinct CUs seen: {len(per_cu)}; workgroups per CU: {np.mean([len(v) for v in per_cu.values()]):.2f}")
+    # how many workgroups does a CU hold at once?  sweep every CU's [entry, last stamp] intervals
+    peak, avg = [], []
+    for idx in per_cu.values():
+        ev = sorted([(t[i, 0], 1) for i in idx] + [(t[i, 4], -1) for i in idx])
+        cur = mx = 0
+        area = 0.0
+        last_t = ev[0][0]
+        for tt, d in ev:
+            area += cur * (tt - last_t)
+            last_t = tt
+            cur += d
+            mx = max(mx, cur)
+        peak.append(mx)
+        avg.append(area / max(1e-9, ev[-1][0] - ev[0][0]))
+    print(f"  workgroups resident per CU at once: peak median {int(np.median(peak))} (min {min(peak)}, max {max(peak)}), time-average {np.mean(avg):.2f}")
     if len(gaps) and not f32:      # fp32 tiles: several workgroups are resident per CU, consecutive ones overlap
         print(f"  {'gap on a CU: last stamp -> next entry':46s} median {np.median(gaps):7.2f} us   p10 {np.percentile(gaps, 10):7.2f}   p90 {np.percentile(gaps, 90):7.2f}")
     starts = np.sort(t[:, 0] - t0)
