@@ -5,6 +5,10 @@ packed detections [-> RCCL all-gather]) at 416x416, batch 64 per GPU, fp32, synt
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...        (no launcher: starts the line above as a child process and relays its JSON line)
+
+--gpus N means N ranks on N GPUs or a non-zero exit: a WORLD_SIZE that differs from N, or fewer than N visible GPUs,
+stops the run without a number.
 
 One rank per GPU; every rank owns 64 images (weak scaling: the path is per-image independent, the only exchange
 is one all-gather of the packed [64,100,7] detections + [64] num_valid per step).  Rank 0 prints ONE JSON line.
@@ -39,8 +43,12 @@ def parity_gate(program, weights, anchors, images_host, device_out, n, M, iou, s
     from oracle import oracle as O
     from oracle import flip_attribution as FA
     from oracle import torch_ref
-    gb, gc, gs, gsel, gnv = (t[:n].cpu().numpy() for t in device_out)
-    rb, rc, rs, rsel, rnv = O.detect(program, weights, images_host[:n], anchors, M, iou, score)
+    # the gate's images come from BOTH ends of the batch: with two sub-batch lanes (the shipped fp32 plan) image 0 runs in
+    # lane 0 and image B-1 in lane 1
+    B = len(images_host)
+    idx = sorted(set(list(range((n + 1) // 2)) + list(range(B - n // 2, B))))
+    gb, gc, gs, gsel, gnv = (t.cpu().numpy()[idx] for t in device_out)
+    rb, rc, rs, rsel, rnv = O.detect(program, weights, images_host[idx], anchors, M, iou, score)
     # The bar: 1e-4 absolute wherever |coord| <= 1 (where detections live), 1e-4 * |coord| for the unclipped boxes tens
     # of image widths wide that random-init heads emit (w = exp(tw) * anchor, reference core/yolo_decode_layer.py:23: a
     # 1e-5 summation-order difference in tw is 1e-5 * w in the corner).  The evidence under the second part is measured
@@ -58,11 +66,11 @@ def parity_gate(program, weights, anchors, images_host, device_out, n, M, iou, s
     flips = FA.attribute(rb, rs, rsel, rnv, gb, gs, gsel, gnv, iou, score)
     if not FA.explained(flips, dev["max_abs_dscore"], dev["max_abs_dbox_coords_within_unit_range"]):
         raise SystemExit(f"PARITY GATE FAILED: end-to-end selection differs without a near-tie: {flips} -- no number reported")
-    tb, tc, ts, tsel, tnv = torch_ref.detect(program, weights, images_host[:n], anchors, M, iou, score)
+    tb, tc, ts, tsel, tnv = torch_ref.detect(program, weights, images_host[idx], anchors, M, iou, score)
     cpu2 = torch_ref.box_deviation(tb, rb, ts, rs)
     cpu2["selection_equal"] = bool(np.array_equal(tsel, rsel) and np.array_equal(tnv, rnv))
     cpu2["what"] = "oracle/torch_ref.py (PyTorch-CPU convolutions) vs oracle/y3_oracle.c on the same images: the floor of fp32 on this input"
-    out = {"images": n}
+    out = {"images": len(idx), "image_indices": idx}
     out.update(dev)
     out.update({"bar": "1e-4 absolute for |coord| <= 1; 1e-4 * |coord| beyond (the raw deviation of two CPU fp32 runs "
                        f"is {cpu2['max_abs_dbox_raw']:.2e} on the same images)",
@@ -168,6 +176,40 @@ def cpu_baseline(program, weights, anchors, images_host, budget_s=20.0):
             "naive_c_port_sample": f"1 image end to end through oracle/y3_oracle.c (scalar loops, OpenMP, {cores} threads)"}
 
 
+def launch_ranks(n, rehearse):
+    """`python bench.py --gpus N` without a launcher: N ranks through torch.distributed.run as a child process, one per GPU.
+    Fails (non-zero, no JSON line) when the box has fewer than N GPUs, unless the gloo rehearsal mode shares them."""
+    import socket
+    import subprocess
+    import torch     # device_count() below does not initialise the GPU
+    have = torch.cuda.device_count()
+    if have < n and not rehearse:
+        print(f"[bench] --gpus {n} needs {n} GPUs, one rank each; this box shows {have} -- no number reported "
+              f"(Y3_BENCH_REHEARSE_GLOO=1 rehearses the control flow with ranks sharing GPUs)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching " + " ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    for ln in r.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0:
+        print(f"[bench] the {n}-rank run exited with status {r.returncode} -- no number reported", file=sys.stderr)
+        return r.returncode
+    if len(lines) != 1:
+        print(f"[bench] expected ONE JSON line from rank 0, got {len(lines)} -- no number reported", file=sys.stderr)
+        return 3
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +238,19 @@ def main():
                     help="skip the in-kernel clock measurement (~1 s of extra forwards after the timed region): profiler runs "
                          "(tools/profile.sh) use it so that every conv launch of the run belongs to a counted step")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # --gpus N means N ranks, or no number.  Without a launcher (no WORLD_SIZE in the environment) and N > 1, this process
+    # becomes the launcher: it starts `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a CHILD
+    # (never an exec; nothing here has touched the GPU yet), relays rank 0's one JSON line and exits with the child's status.
+    rehearse = os.environ.get("Y3_BENCH_REHEARSE_GLOO") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, rehearse))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks: one rank per GPU, "
+                         f"--gpus must equal --nproc-per-node -- no number reported")
 
     # host threads for the CPU legs (oracle parity gate, cpu_baseline): this process's real CPU share, fixed before any
     # OpenMP runtime starts (torch's and the oracle's both read the environment once)
@@ -226,7 +281,9 @@ def main():
     # two ranks on the build box's one GPU) -- ranks share devices, the process group is gloo and the gather goes through host
     # copies.  It checks sharding, the rank-order gate, the barriers and the max-over-ranks timing; it is NOT a measurement (the
     # line says so in config.collective) and RCCL itself needs one GPU per rank.
-    rehearse = os.environ.get("Y3_BENCH_REHEARSE_GLOO") == "1"
+    if not rehearse and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"[bench] rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible: one rank "
+                         f"per GPU -- no number reported")
     torch.cuda.set_device(local_rank % torch.cuda.device_count() if rehearse else local_rank)
     use_dist = world > 1 or os.environ.get("Y3_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL with one rank
     if use_dist:
@@ -410,15 +467,25 @@ def main():
     # partial products issued per fp32 product: six bf16 (three planes) or three fp16 (two planes)
     mfma_flops_factor = {"f32x3": 6.0, "f32x2": 3.0}.get(args.dtype, 1.0)
 
-    traffic = None
-    tf_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_traffic_{args.dtype}_b{B}_s{S}.json")
-                                for r in range(9, 0, -1)) if os.path.exists(q)), "")
-    traffic_source = None
-    if tf_path:   # PMC-derived HBM bytes per conv-stack pass, measured by tools/profile.sh on this workload (latest round)
+    # roofline.traffic: PMC-derived HBM bytes per conv-stack pass, measured by tools/profile.sh on this workload -- taken from
+    # the newest profiles/rNN_traffic_<dtype>_b<B>_s<S>.json.  The line names the round of that file (traffic_round) and calls
+    # it stale when a later round's kernel profile exists (the kernels changed after the bytes were counted).
+    import glob
+    import re
+    traffic, traffic_source, traffic_round = None, None, None
+    rounds = sorted((int(m.group(1)), q) for q in glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{args.dtype}_b{B}_s{S}.json"))
+                    for m in [re.match(r"r(\d+)_", os.path.basename(q))] if m)
+    if rounds:
+        traffic_round, tf_path = rounds[-1]
         with open(tf_path) as f:
             traffic = json.load(f).get("conv_stack_hbm_bytes_per_step")
+        newest = max([int(m.group(1)) for q in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats.txt"))
+                      for m in [re.match(r"r(\d+)_", os.path.basename(q))] if m] or [traffic_round])
         traffic_source = (f"{os.path.relpath(tf_path, ROOT)}: rocprofv3 --pmc passes of tools/profile.sh on this workload in an "
-                          f"earlier run (FETCH_SIZE doubled per the guide + WRITE_SIZE), NOT measured in this run")
+                          f"earlier run of round {traffic_round} (FETCH_SIZE doubled per the guide + WRITE_SIZE), NOT measured in this run")
+        if newest > traffic_round:
+            traffic_source = (f"STALE: counted in round {traffic_round}, the newest kernel profile is round {newest}'s (other kernels "
+                              f"since) -- ") + traffic_source
     # Extra information on the default (f32) line: the same workload in the fp32-accurate three-plane mode (bf16 matrix
     # cores, same parity tests as f32).  Not the headline value.
     alts = {}
@@ -484,7 +551,7 @@ def main():
                                             else "conv stack (fused stem kernel = conv0..2 in one launch + 72 x conv_bf16_mfma launches per step and lane)" if args.dtype == "bf16"
                                             else f"conv stack (74 x conv_f32x3_mfma{'<2 planes>' if args.dtype == 'f32x2' else ''} launches + 1 first-layer conv per step)"),
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved * mfma_flops_factor / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "frac": round(achieved * mfma_flops_factor / peak, 4), "traffic": traffic, "traffic_round": traffic_round, "traffic_source": traffic_source,
                 "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None, "sclk_source": sclk_src,
                 "frac_of_clock_limited_peak": (round(achieved * mfma_flops_factor / (peak * sclk_mhz / 2400.0), 4)
                                                if sclk_mhz else None),

@@ -14,7 +14,8 @@
  *     "host" pointers are ordinary host memory, copied during the call.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
  *     synchronises the device unless stated.  A y3_net is bound to the device that was current
- *     at creation and is not thread-safe.
+ *     at creation and is not thread-safe.  Calls on a net (plan, weights, forward, detect, measure) run on the
+ *     net's device whatever the caller's current device is and leave the caller's current device as they found it.
  *   - tensors are NHWC fp32 unless stated; boxes are normalised (xmin,ymin,xmax,ymax).
  */
 #ifndef Y3_H
@@ -45,10 +46,10 @@ int y3_version(void);
 const char *y3_last_error(void);
 /* number of visible HIP devices (0 when none); never fails */
 int y3_device_count(void);
-/* 1 when tile id `tile` of the conv kernel family of `dtype` (Y3_DTYPE_*) is compiled into this library, else 0.
- * The default build carries the tiles a tuning table or heuristic can select; timing-only probes, the stream-K
- * schedule (fp32 33..40), the residual-prefetch variants (fp32 41..45) and the pipelined bf16 tile (20) were measured
- * and lost and exist only in libraries built with csrc/build.py --experimental. */
+/* 1 when tile id `tile` of the conv kernel family of `dtype` (Y3_DTYPE_*) exists in this library, else 0.  Tile ids are stable
+ * (tuning tables refer to them); the ids of tiles that were measured and lost in rounds 1-3 (timing-only ablations, the
+ * stream-K schedule, residual prefetch, the pipelined bf16 tile; DESIGN.md section 4, records under profiles/) are retired
+ * and answer 0. */
 int y3_tile_built(int dtype, int tile);
 
 /* ------------------------------------------------------------------------------------------
@@ -120,12 +121,6 @@ y3_status y3_net_set_tile_x2(y3_net *net, int conv_slot, int tile);   /* same ti
  * stream: the tail of one sub-batch's conv kernel overlaps the next kernel of another.  Results are unchanged
  * (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
 y3_status y3_net_set_lanes(y3_net *net, int lanes);
-/* (experimental builds only, see y3_tile_built) fp32 tiles 33..40 run the persistent "stream-K" schedule: as many workgroups as the chip holds at once, each with an
- * equal share of the (tile, K-tile) iterations; tiles cut between workgroups are summed through fp32 slabs in a
- * net-owned workspace in a fixed order (run-to-run deterministic; the split points depend on the launch geometry, so the
- * last bits of an image's result may depend on the batch it is in -- the classic tiles 0..32 never split a sum).
- * y3_net_set_sk_grid: force the number of persistent workgroups (0 = everything resident at once); for tests. */
-y3_status y3_net_set_sk_grid(y3_net *net, int workgroups);
 /* Placement of the fp32 conv tiles on the 8 XCDs (each has a private 4 MB L2).  1 (default): per conv, the XCDs form an
  * (8/gn) x gn grid over the (pixel-tile, channel-tile) matrix, gn chosen so that an XCD's slice of the weights stays in
  * its L2 (the 256->512 / 512->1024 3x3 weights are 4.7 / 18.9 MB); 0: every XCD takes a contiguous run of tiles.
@@ -142,13 +137,18 @@ y3_status y3_net_keep_activations(y3_net *net, int keep);
  * the two run as ONE kernel that keeps conv0's output (the largest tensor of the network, 1.4 GB at 64 x 416^2) in LDS; the
  * 1x1 conv that follows (64 -> 32, backbone.yaml layer 3) is computed by the same kernel from conv1's tile.
  * 2: conv0 + conv1 in one kernel, the 1x1 conv as its own launch (bf16 plans: bit-identical to 1).
- * 0: one launch per conv.  Results agree to fp32 rounding (conv0's summation order differs between the two kernels). */
+ * 0: one launch per conv.  fp32 plans: results agree to fp32 rounding (conv0's summation order differs between the two
+ * kernels).  bf16 plans: the fused kernel forms conv0's products on the bf16 matrix cores from operands split x = hi + lo
+ * (hi*hi + hi*lo + lo*hi, fp32 accumulation: ~2^-16 relative error per product, NOT fp32 arithmetic) and rounds the result to
+ * bf16 where the pipeline stores it; against the one-launch-per-conv form a fraction of a percent of conv0's bf16 values round
+ * the other way (bounded by tests/test_gpu_parity.py::test_fused_stem_bf16_matches_oracle_and_the_two_launch_form). */
 y3_status y3_net_set_stem_fusion(y3_net *net, int on);
 /* Measurement aid (bench.py): the shader clock the chip holds under this network's load.  Runs `forwards` forwards back to
  * back (grids_dev as for y3_net_forward); in the last one, thread 0 of the middle workgroup of the conv with the most FLOPs (fp32
  * plans: an MFMA conv launch; bf16 plans: the fused stem kernel) reads s_memtime and s_memrealtime at its entry and after
  * its epilogue: MHz = d(memtime) / d(memrealtime) x 100 (MI355X_MICROARCH.md, DVFS give-back item 6).  Synchronises the
- * stream.  No product launch carries stamps (the kernels test a null pointer). */
+ * stream.  No product launch carries stamps (the kernels test a null pointer).  The three measure_sclk calls temporarily
+ * change the net's lane count and stamp fields: never run them concurrently with a forward on the same net. */
 y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
                               float *mhz_out, void *stream);
 /* The same measurement on the launch of conv slot `conv` (tools/sclk_per_layer.py: the clock differs from layer to layer

@@ -91,23 +91,19 @@ def test_rccl_not_loadable_is_a_status_not_a_crash():
 
 
 def test_tile_built_reports_the_default_tile_set():
-    """y3_tile_built (no GPU needed): the default library holds exactly the tiles a tuning table or heuristic can pick;
-    probes, stream-K, residual prefetch and the pipelined bf16 tile exist only in csrc/build.py --experimental."""
+    """y3_tile_built (no GPU needed): the library holds exactly the tiles of the Python-side tables; the ids of the ablations and
+    schedules that lost their A/Bs in rounds 1-3 (probes, stream-K, residual prefetch, the pipelined bf16 tile) are retired."""
     from yolo_v3_tf2_amd import _lib
-    exp = _lib.tile_built(_lib.Y3_DTYPE_F32, 33)
-    f32 = [t for t in range(len(_lib.TILES)) if _lib.tile_built(_lib.Y3_DTYPE_F32, t)]
-    bf16 = [t for t in range(len(_lib.TILES_BF16)) if _lib.tile_built(_lib.Y3_DTYPE_BF16, t)]
-    x2 = [t for t in range(len(_lib.TILES_X3)) if _lib.tile_built(_lib.Y3_DTYPE_F32X2, t)]
-    x3 = [t for t in range(len(_lib.TILES_X3)) if _lib.tile_built(_lib.Y3_DTYPE_F32X3, t)]
+    f32 = [t for t in range(len(_lib.TILES) + 16) if _lib.tile_built(_lib.Y3_DTYPE_F32, t)]
+    bf16 = [t for t in range(len(_lib.TILES_BF16) + 4) if _lib.tile_built(_lib.Y3_DTYPE_BF16, t)]
+    x2 = [t for t in range(len(_lib.TILES_X3) + 16) if _lib.tile_built(_lib.Y3_DTYPE_F32X2, t)]
+    x3 = [t for t in range(len(_lib.TILES_X3) + 16) if _lib.tile_built(_lib.Y3_DTYPE_F32X3, t)]
     assert not _lib.tile_built(_lib.Y3_DTYPE_F32, -1) and not _lib.tile_built(_lib.Y3_DTYPE_F32, len(_lib.TILES))
     assert not _lib.tile_built(7, 0)
-    assert x3 == list(_lib.TILES_X3_BUILT)
-    if exp:
-        assert f32 == list(range(len(_lib.TILES))) and bf16 == list(range(len(_lib.TILES_BF16)))
-        assert x2 == sorted(_lib.TILES_X2_BUILT + _lib.PROBE_TILES_X2)
-    else:
-        assert f32 == list(range(20)) + [23, 24] + list(range(26, 33)) and bf16 == list(range(20)) + list(range(21, len(_lib.TILES_BF16)))
-        assert x2 == list(_lib.TILES_X2_BUILT)
+    assert x3 == list(_lib.TILES_X3_BUILT) and x2 == list(_lib.TILES_X2_BUILT)
+    assert f32 == [t for t in range(len(_lib.TILES)) if _lib.TILES[t][0] > 0] == list(range(20)) + [23, 24] + list(range(26, len(_lib.TILES)))
+    assert bf16 == [t for t in range(len(_lib.TILES_BF16)) if _lib.TILES_BF16[t][0] > 0] == list(range(20)) + list(range(21, 32))
+    assert _lib.RETIRED_TILES == (20, 21, 22, 25)
     # every tile a committed tuning table names is in the default set
     import glob
     import json

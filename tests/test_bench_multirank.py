@@ -36,3 +36,53 @@ def test_bench_two_ranks_rehearsal(extra, scaling, global_batch):
     assert d["config"]["collective"].startswith("REHEARSAL")
     assert d["parity_checked"] == 2 and d["parity"]["nms_index_selection"].startswith("bit-exact")
     assert d["value"] > 0 and abs(d["value"] - global_batch * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) <= 0.02 * d["value"]
+
+
+def _bench(args, env_extra=None, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_gpus_n_without_enough_gpus_exits_nonzero_naming_the_shortfall():
+    """`python bench.py --gpus 8` used to run ONE rank and print n_gpus 1 with rc 0.  Now --gpus N means
+    N ranks on N GPUs or no number.  Runs anywhere: more ranks than any box has GPUs."""
+    r = _bench(["--gpus", "64", "--steps", "1", "--warmup", "1"])
+    assert r.returncode != 0
+    assert "--gpus 64 needs 64 GPUs" in r.stderr and "no number reported" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_gpus_n_must_equal_the_launchers_world_size():
+    r = _bench(["--gpus", "8", "--steps", "1", "--warmup", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 8 but the launcher started WORLD_SIZE=2" in r.stderr
+    assert not r.stdout.strip()
+    r = _bench(["--gpus", "1", "--steps", "1", "--warmup", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 1 but the launcher started WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_launcherless_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (child process), relays ONE JSON line."""
+    r = _bench(["--gpus", "2", "--batch", "4", "--image-size", "96", "--steps", "3", "--warmup", "1", "--no-alt",
+                "--no-cpu-baseline", "--no-sclk"], {"Y3_BENCH_REHEARSE_GLOO": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["rank_order_checked"] is True
+    assert d["config"]["collective"].startswith("REHEARSAL") and d["parity_checked"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_on_a_one_gpu_box_fails_loudly():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with one GPU")
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1"])
+    assert r.returncode != 0 and "--gpus 2 needs 2 GPUs" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]

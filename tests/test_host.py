@@ -159,3 +159,23 @@ def test_bench_bf16_parity_gate_passes_the_floor_and_rejects_garbage(program, we
     noisy = [g * torch.from_numpy((1.0 + 0.05 * rng.standard_normal(tuple(g.shape))).astype(np.float32)) for g in alt]
     with pytest.raises(SystemExit, match="PARITY GATE FAILED"):
         bench.parity_gate_bf16(program, weights, x, noisy, 1)
+
+
+def test_tuning_override_applies_only_to_the_plan_it_names(tmp_path, monkeypatch):
+    """Y3_TUNING_FILE used to replace the table of EVERY plan in the process (bench.py's alt measurements re-plan
+    the net in f32x3 / f32x2 and would have received fp32 tile ids).  The override now names its mode and geometry."""
+    import json
+    from yolo_v3_tf2_amd import PACKAGE_DIR
+    from yolo_v3_tf2_amd.runtime import tuning_table_path
+    packaged = os.path.join(PACKAGE_DIR, "tuning", "f32_b64_s416.json")
+    monkeypatch.delenv("Y3_TUNING_FILE", raising=False)
+    assert tuning_table_path("f32", 64, 416) == packaged
+    f = tmp_path / "t.json"
+    f.write_text(json.dumps({"dtype": "f32", "batch": 64, "image_size": 416, "lanes": 1, "tiles": {}}))
+    monkeypatch.setenv("Y3_TUNING_FILE", str(f))
+    assert tuning_table_path("f32", 64, 416) == str(f)
+    assert tuning_table_path("f32x2", 64, 416).endswith("tuning/f32x2_b64_s416.json")      # another mode: packaged table
+    assert tuning_table_path("f32", 32, 416).endswith("tuning/f32_b32_s416.json")          # another batch
+    assert tuning_table_path("f32", 64, 608).endswith("tuning/f32_b64_s608.json")          # another image size
+    f.write_text(json.dumps({"batch": 64, "image_size": 416, "tiles": {}}))                 # no mode named: never applied
+    assert tuning_table_path("f32", 64, 416) == packaged

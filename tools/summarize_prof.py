@@ -13,12 +13,13 @@ def short(name):
     if m:
         tm, tn, wr, wc, cat, st = map(int, m.groups())
         return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{st}{',cat' if cat else ''}>"
-    m = re.search(r"conv_f32_mfma<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, (\d+), (\d+), (true|false|\d))?(?:, (\d))?", name)
+    # template <TM, TN, WR, WC, CONCAT, STAGES, MINW, DMA, ...> (round 4; the probe / stream-K / residual-prefetch parameters are gone)
+    m = re.search(r"conv_f32_mfma<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)(?:, (\d+), (\d+))?((?:, \d+)*)>", name)
     if m:
         tm, tn, wr, wc = (int(m.group(i)) for i in range(1, 5))
-        dma = ",dma" if m.group(9) in ("true", "1") else ""
-        sk = ",streamk" if m.group(10) == "1" else ""
-        return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{m.group(6)}{dma}{sk}{',cat' if m.group(5) == 'true' else ''}>"
+        dma = ",dma" if m.group(8) == "1" else ""
+        extra = "".join(",x" + v.strip() for v in m.group(9).split(",") if v.strip() and v.strip() != "0")
+        return f"conv_f32_mfma<{32*tm*wr}x{32*tn*wc},w{wr*wc},s{m.group(6)}{dma}{extra}{',cat' if m.group(5) == 'true' else ''}>"
     m = re.search(r"conv_bf16_mfma<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(?:, (true|false), (\d+), (true|false))?", name)
     if m:
         tm, tn, wr, wc, bk = (int(m.group(i)) for i in range(1, 6))

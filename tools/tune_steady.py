@@ -51,6 +51,7 @@ def main():
     setter = {"f32": net.set_tile, "bf16": net.set_tile_bf16, "f32x3": net.set_tile_x3, "f32x2": net.set_tile_x2}[a.dtype]
     path = os.path.join(ROOT, "yolo-v3-tf2_amd", "tuning", f"{a.dtype}_b{B}_s{S}.json")
     doc = json.load(open(path)) if os.path.exists(path) else {"batch": B, "image_size": S, "tiles": {}}
+    doc["dtype"] = a.dtype
     table = dict(doc.get("tiles", {}))
     x = torch.rand((B, S, S, 3), device="cuda")
     sigs = {}

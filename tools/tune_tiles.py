@@ -28,13 +28,6 @@ def main():
     ap.add_argument("--write", type=str, default="")
     ap.add_argument("--dtype", choices=["f32", "bf16", "f32x3", "f32x2"], default="f32")
     a = ap.parse_args()
-    from yolo_v3_tf2_amd import _lib as _l
-    asked = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else []
-    probes_asked = [t for t in asked if t in (_l.PROBE_TILES_X2 if a.dtype == "f32x2" else _l.PROBE_TILES if a.dtype == "f32" else ())]
-    if probes_asked:
-        if a.write:
-            sys.exit(f"tiles {probes_asked} are timing-only probes (wrong results): refusing --write")
-        os.environ["Y3_ALLOW_PROBE_TILES"] = "1"     # read by y3_net_set_tile / y3_net_set_tile_x2
     B, S = a.batch, a.image_size
     p = load_program(os.path.join(ROOT, "config/models/yolov3/model.yaml"), 80)
     w = synthetic_weights(p)
@@ -49,20 +42,14 @@ def main():
                     "f32x2": _lib.Y3_DTYPE_F32X2}[a.dtype])
     x = torch.rand((B, S, S, 3), device="cuda")
     TL = _lib.TILES_X3 if x3 else _lib.TILES_BF16 if bf else TILES
-    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("pipe" if (i == 20 and not x3) else "d" if (i >= 8 and not x3) else "") + ("s1" if (x3 and i in (9, 10, 11, 13, 14, 15)) else "") + ("i" if (x3 and 20 <= i < 26) else "") + ("p" if (x3 and i in (28, 29)) else "") + ("s3" if (x3 and 30 <= i < 34) else "") + ("sk" if (x3 and 34 <= i < 37) else "") + ("nold" if (x3 and 37 <= i < 40) else "") + ("ld" if (x3 and 40 <= i < 43) else "") + ("a1" if (x3 and i >= 43) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
+    TN_ = [f"{bm}x{bn}w{w}k{k}" + ("d" if (i >= 8 and not x3) else "") + ("s1" if (x3 and i in (9, 10, 11, 13, 14, 15)) else "")
+           + ("i" if (x3 and 20 <= i < 26) else "") + ("s3" if (x3 and 30 <= i < 34) else "") for i, (bm, bn, w, k) in enumerate(TL)] if bf else TILE_NAMES
     tiles = [int(t) for t in a.tiles.split(",")] if a.tiles != "all" else list(range(len(TL)))
-    if a.tiles == "all":   # timing-only probe tiles (wrong results) must be asked for by id; never with --write
-        probes = _lib.PROBE_TILES_X2 if x2 else () if bf else _lib.PROBE_TILES
-        tiles = [t for t in tiles if t not in probes]
     dt_id = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3, "f32x2": _lib.Y3_DTYPE_F32X2}[a.dtype]
     missing = [t for t in tiles if not _lib.tile_built(dt_id, t)]
     if missing and a.tiles != "all":
-        sys.exit(f"tiles {missing} are not in this library: build csrc/build.py --experimental and set Y3_LIB_PATH")
-    tiles = [t for t in tiles if _lib.tile_built(dt_id, t)]     # experimental tiles only when the loaded library has them
-    if x2:
-        tiles = [t for t in tiles if t in _lib.TILES_X2_BUILT + _lib.PROBE_TILES_X2]
-    elif x3:
-        tiles = [t for t in tiles if t in _lib.TILES_X3_BUILT]
+        sys.exit(f"tile ids {missing} do not exist in this library (retired ids: y3_tile_built)")
+    tiles = [t for t in tiles if _lib.tile_built(dt_id, t)]
     res = {}
     for t in [-1] + tiles:
         bn = TL[t][1] if t >= 0 else 0
@@ -117,7 +104,7 @@ def main():
         d = os.path.join(ROOT, "yolo-v3-tf2_amd", "tuning")
         os.makedirs(d, exist_ok=True)
         path = os.path.join(d, a.write)
-        doc = {"batch": B, "image_size": S, "tiles": winners}
+        doc = {"dtype": a.dtype, "batch": B, "image_size": S, "tiles": winners}
         if os.path.exists(path):     # keep the keys other tools own (lanes: tools/lanes_sweep.py)
             with open(path) as f:
                 old = json.load(f)

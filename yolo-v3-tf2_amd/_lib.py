@@ -19,27 +19,18 @@ Y3_DTYPE_F32, Y3_DTYPE_BF16, Y3_DTYPE_F32X3, Y3_DTYPE_F32X2 = 0, 1, 2, 3
 DTYPE_TAGS = {Y3_DTYPE_F32: "f32", Y3_DTYPE_BF16: "bf16", Y3_DTYPE_F32X3: "f32x3", Y3_DTYPE_F32X2: "f32x2"}
 TILES_X2_BUILT = (0, 1, 2, 3, 4, 6, 8, 9, 10, 12, 26, 27, 30, 31, 32, 33)
 TILES_X3_BUILT = tuple(range(28)) + (30,)
-PROBE_TILES_X2 = (28, 29, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45)   # timing-only ablations, accepted by set_tile_x2, never chosen by the library   # ids of TILES_X3 instantiated for the two-plane mode
 Y3_AUX_ADD, Y3_AUX_UPSAMPLE2X, Y3_AUX_CONCAT = 0, 1, 2
 # (BM, BN, waves, LDS stages) of every tile id of the fp32 MFMA conv kernel (mirror of kTiles in csrc/conv_f32.hip)
 TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (64, 128, 4, 2), (64, 64, 4, 2),
          (128, 128, 4, 1), (256, 64, 4, 1), (256, 32, 4, 1), (128, 64, 4, 1), (64, 128, 4, 1), (64, 64, 4, 1),
          (128, 128, 8, 1), (128, 128, 8, 2), (128, 128, 16, 1), (128, 128, 16, 2),
          (256, 128, 16, 1), (128, 64, 8, 1), (256, 64, 8, 1), (128, 64, 8, 2),
-         (64, 128, 4, 1), (64, 128, 4, 1), (64, 128, 4, 1),  # 20..22: timing-only probes (wrong results)
+         (0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0),           # 20..22: retired ids (y3_tile_built answers 0)
          (128, 128, 4, 1), (128, 128, 4, 1),                # 23/24: 128x128 within 3 / 4 waves per SIMD of registers
-         (64, 128, 4, 1),                                   # 25: probe 4 (timing only)
+         (0, 0, 0, 0),                                      # 25: retired id
          (64, 128, 4, 2), (64, 64, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (256, 32, 4, 2),  # 26..30: LDS-DMA operand loads
-         (64, 128, 4, 1), (64, 64, 4, 1),                   # 31, 32: LDS-DMA, single LDS stage
-         # 33..40: the persistent stream-K schedule of tiles 10, 11, 9, 17, 26, 27, 31, 32
-         (64, 128, 4, 1), (64, 64, 4, 1), (128, 64, 4, 1), (128, 64, 8, 1),
-         (64, 128, 4, 2), (64, 64, 4, 2), (64, 128, 4, 1), (64, 64, 4, 1),
-         # 41..45: residual prefetch variants of tiles 10, 31, 27, 11, 26 (identical results; other convs run the base tile)
-         (64, 128, 4, 1), (64, 128, 4, 1), (64, 64, 4, 2), (64, 64, 4, 1), (64, 128, 4, 2)]
-RESPF_BASE = {41: 10, 42: 31, 43: 27, 44: 11, 45: 26}
-SK_TILES = tuple(range(33, 41))
-SK_BASE = {33: 10, 34: 11, 35: 9, 36: 17, 37: 26, 38: 27, 39: 31, 40: 32}
-N_REAL_TILES = 20
+         (64, 128, 4, 1), (64, 64, 4, 1)]                   # 31, 32: LDS-DMA, single LDS stage
+RETIRED_TILES = tuple(i for i, t in enumerate(TILES) if t[0] == 0)   # ids y3_tile_built answers 0 for
 # three-plane (fp32-accurate on bf16 MFMA) kernel tiles: (BM, BN, waves, BK)
 TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), (256, 64, 4, 32),
             (128, 64, 4, 64), (64, 64, 4, 64), (128, 256, 8, 32),
@@ -49,27 +40,20 @@ TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 3
             (256, 128, 8, 32), (128, 256, 8, 32), (128, 128, 4, 32), (128, 128, 8, 32),   # 20..23: interleaved DMA issue
             (256, 128, 8, 32), (128, 256, 8, 32),                                         # 24..25: + pinned issue order
             (256, 128, 16, 32), (128, 256, 16, 32),                                       # 26..27: 16 waves
-            (256, 128, 16, 32), (128, 128, 8, 32),                                        # 28..29: two-plane timing probes (wrong results)
-            (128, 128, 8, 32), (256, 128, 16, 32), (256, 128, 8, 32), (128, 256, 16, 32),  # 30..33: three LDS stages
-            (256, 128, 16, 32), (128, 128, 8, 32), (256, 128, 8, 32),                      # 34..36: two-plane split-K timing probes (wrong results)
-            (256, 128, 16, 32), (128, 128, 8, 32), (256, 128, 8, 32),                      # 37..39: two-plane no-fetch timing probes (wrong results)
-            (128, 64, 4, 32), (128, 64, 4, 64), (128, 128, 8, 32),                         # 40..42: two-plane fetch-only timing probes (wrong results)
-            (256, 256, 16, 32), (256, 128, 16, 32), (256, 128, 8, 32)]                     # 43..45: two-plane one-accumulator timing probes (wrong results)
+            (0, 0, 0, 32), (0, 0, 0, 32),                                                 # 28..29: retired ids
+            (128, 128, 8, 32), (256, 128, 16, 32), (256, 128, 8, 32), (128, 256, 16, 32)]  # 30..33: three LDS stages
 # bf16 kernel tiles: (BM, BN, waves, BK)
 TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
               (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64),
               (128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (64, 128, 4, 64), (128, 256, 8, 64),  # 8..13: LDS-DMA loads
               (256, 256, 8, 64), (256, 128, 4, 64), (128, 256, 4, 64),  # 14..16: LDS-DMA, bigger wave tiles
               (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64),  # 17..19: LDS-DMA, 16 waves
-              (256, 256, 8, 64),  # 20: pipelined K loop (prefetch in flight across raw barriers, counted vmcnt)
+              (0, 0, 0, 64),      # 20: retired id (the pipelined tile of round 2)
               (128, 256, 8, 32), (256, 128, 8, 32), (128, 128, 4, 32),  # 21..23: LDS-DMA, BK 32: several workgroups per CU
               (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64),  # 24..26: tiles 17..19 on 16x16x32 MFMAs
               (128, 128, 4, 64), (128, 64, 4, 64), (64, 128, 4, 64),       # 27..29: tiles 8, 10, 12 on 16x16x32 MFMAs
               (128, 64, 4, 32), (64, 64, 4, 32)]                          # 30, 31: LDS-DMA, BK 32, 64 output channels
-TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if (26 <= i <= 32 or 37 <= i <= 40 or i in (42, 43, 45)) else "")
-              + ("sk" if 33 <= i <= 40 else "") + ("rp" if i >= 41 else "")
-              for i, (bm, bn, w, st) in enumerate(TILES)]
-PROBE_TILES = (20, 21, 22, 25)  # timing-only ablations, wrong results
+TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
 
 
 class Y3Error(RuntimeError):
@@ -110,7 +94,6 @@ SYMBOLS = {
     "y3_net_set_early_chunk": (_i, [_vp, _i, _i]),
     "y3_net_keep_activations": (_i, [_vp, _i]),
     "y3_net_set_lanes": (_i, [_vp, _i]),
-    "y3_net_set_sk_grid": (_i, [_vp, _i]),
     "y3_net_set_xcd_mode": (_i, [_vp, _i]),
     "y3_net_set_k_chunk": (_i, [_vp, _i]),
     "y3_net_set_stem_fusion": (_i, [_vp, _i]),
@@ -159,7 +142,7 @@ def load():
 
 
 def tile_built(dtype: int, tile: int) -> bool:
-    """False for the experimental tiles (probes, stream-K, residual prefetch, pipelined bf16) a default build omits."""
+    """False for a retired tile id (the ablations / schedules that lost their A/Bs in rounds 1-3 and were removed)."""
     return bool(load().y3_tile_built(int(dtype), int(tile)))
 
 

@@ -67,18 +67,8 @@ def _build_variant(defines, out, only, verbose):
     return out
 
 
-def build_experimental(verbose=False):
-    """The library with every experimental tile compiled in (-DY3_EXPERIMENTAL: timing probes, stream-K, residual
-    prefetch, the pipelined bf16 tile) as lib/liby3hip_exp.so; load it with Y3_LIB_PATH.  The default library and the
-    driver's build() never contain these (VERDICT r02 #8): they lost their A/Bs and cost minutes of compile time."""
-    return _build_variant(["Y3_EXPERIMENTAL"], OUT.replace(".so", "_exp.so"),
-                          ["conv_f32.hip", "conv_bf16.hip", "conv_f32x3.hip"], verbose)
-
-
 if __name__ == "__main__":
-    if "--experimental" in sys.argv:
-        print(build_experimental(verbose=True))
-    elif "--variant" in sys.argv:                # build.py --variant OUT.so SRC.hip -DNAME[=V] ...
+    if "--variant" in sys.argv:                # build.py --variant OUT.so SRC.hip -DNAME[=V] ...
         i = sys.argv.index("--variant")
         out_, src_ = sys.argv[i + 1], sys.argv[i + 2]
         print(build(defines=[a[2:] for a in sys.argv[i + 3:] if a.startswith("-D")], out=os.path.abspath(out_), only=[src_], verbose=True))

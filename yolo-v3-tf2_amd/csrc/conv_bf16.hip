@@ -284,11 +284,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
     // ---- epilogue through LDS, one 32-row sub-tile of every wave per pass ----------------------------------
     // pass i: wave (wr, wc) writes rows [wr*32, +32) x cols [wc*32*TN, +32*TN) of a [WR*32][BN+4] fp32 tile (its i-th
     // accumulator row block), then all threads convert 8 consecutive channels each and store 16 B.
-#ifdef Y3_AB_PROBE_NO_EPILOGUE
-    // timing-only A/B build (tools/ab_libs.py): what does the epilogue cost?  The condition is always true at run time, but
-    // opaque to the compiler: the epilogue stays in the binary (same registers, same code layout) and never runs.
-    if (p.leaky >= 0) return;
-#endif
     if constexpr (!OUT_F32) {
         // ---- bf16 output: per-wave epilogue, no workgroup barrier ------------------------------------------------------
         // Every wave transposes its own 32 x (32 TN) fp32 blocks through a private LDS scratch (the operand tiles are dead
@@ -315,11 +310,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
         for (int i = 0; i < TM; ++i) {
             const int mw = m0 + (wr * TM + i) * 32;   // first row of this block
             u32x4 rr[NPL];
-#ifdef Y3_AB_PROBE_NO_RESLOAD
-            if (res && p.leaky < 0) {   // timing-only A/B build: the shortcut loads never execute
-#else
             if (res) {   // shortcut operand first: its latency hides behind the accumulator write-out
-#endif
 #pragma unroll
                 for (int it = 0; it < NPL; ++it) {
                     const int q = lane + it * 64;
@@ -350,6 +341,11 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
                     }
                 }
             }
+            // lanes read what OTHER lanes of this wave wrote: the hardware runs a wave's LDS operations in order, and these three
+            // builtins (no instructions) keep the compiler from moving the reads above the writes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int it = 0; it < NPL; ++it) {
                 const int q = lane + it * 64;
@@ -367,11 +363,12 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
                 u32x4 out;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) out[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
-#ifdef Y3_AB_PROBE_NO_STORE
-                if (p.leaky < 0)   // timing-only A/B build: never true at run time (opaque to the compiler): no output store executes
-#endif
                 if (mw + r < p.M) *reinterpret_cast<u32x4 *>(dstb + (size_t)(mw + r) * p.Cout + nw + pc * 8) = out;
             }
+            // ... and the next pass's writes below this pass's reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         Y3_STAMP(4);   // thread 0 = wave 0: its own stores issued (not yet retired)
     } else {
@@ -426,262 +423,11 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
 // during the K loops.  What would help is out-of-phase workgroups (two per CU), which this tile's LDS and register
 // budget do not admit.
 // ---------------------------------------------------------------------------------------------------------
+// Round-2 record (code removed in round 4): a pipelined 256x256x64 tile (id 20) with the K loop of the guide's "256^2 8-phase
+// template" (LDS-DMA loads in flight across raw s_barriers, counted vmcnt, the second M half of the waves one barrier behind
+// the first) was correct on the first build and 10-15 % SLOWER than the 16-wave two-phase tile 17
+// (profiles/r02_tile_sweep_bf16_pipelined_b128_s416.txt, r02_bf16_pipelined_tile_pmc.txt: MFMA busy 0.45 vs 0.58).
 // ---------------------------------------------------------------------------------------------------------
-// Pipelined 256x256x64 tile (tile id 20): the K loop of cdna_hip_programming.md section 5 "256^2 8-phase template",
-// adapted to the implicit-GEMM gather.  8 waves (2 along M x 4 along N), 128x64 per wave, 128 KB of LDS = two K-tile
-// buffers of four 16-KB half-tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255), filled by LDS-DMA loads that stay
-// in flight ACROSS barriers: raw s_barrier + counted s_waitcnt vmcnt instead of __syncthreads() (whose vmcnt(0)
-// drains the prefetch every K step -- the ~900 TFLOP/s ceiling of the two-barrier loop above).
-// A K tile is four phases; each phase = (ds_reads of its fragments | DMA issue) barrier (8 MFMAs) barrier:
-//   P0: read A(m 0,1) + B(n 0); stage both A half-tiles of K tile t+1 into the OTHER buffer   -> MFMA (m 0,1) x n0
-//   P1: read B(n 1)                                                                           -> MFMA (m 0,1) x n1
-//   P2: read A(m 2,3)                                                                         -> MFMA (m 2,3) x n1
-//   P3: wait for this wave's loads (issued 3 and 4 phases ago); stage both B half-tiles of K tile t+2 into THIS
-//       buffer                                                          [no LDS reads]        -> MFMA (m 2,3) x n0
-// The four waves of the second M half run one barrier behind the first half (each SIMD holds one wave of either
-// half): while one issues its 8 MFMAs the other issues its LDS reads and DMA loads.
-// RAW: a K tile is read from P0 on, one barrier pair after the wait of the preceding P3 (two intervals later for the
-// staggered half, whose own wait is one interval later).  WAR: a half-tile is restaged two phases after its last read.
-// Limits: Cin % 64 == 0, CoutPad % 256 == 0, no concat source, bf16 output (residual optional), K / 64 >= 2.
-// ---------------------------------------------------------------------------------------------------------
-#ifdef Y3_EXPERIMENTAL
-__global__ __launch_bounds__(512) void conv_bf16_pipe(const ConvArgs p)
-{
-    constexpr int TM = 4, TN = 2, WR = 2, BK = 64;     // 2 x 4 waves, 128 x 64 per wave
-    constexpr int BM = 256, BN = 256, NT = 512;
-    constexpr int ROWB = 128;                 // bytes per LDS row (64 bf16), unpadded: XOR-swizzled 16-B chunks
-    constexpr int HALF_B = 128 * ROWB;        // one half-tile: 16 KB
-    constexpr int BUF_B = 4 * HALF_B;         // A0, A1, B0, B1
-    constexpr int CROW = BN + 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tilesN = p.CoutPad / BN;
-    const int mt = logical / tilesN, nt = logical - mt * tilesN;
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    const __amdgpu_buffer_rsrc_t rs0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.src0), 0, p.src0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wpk), 0, p.w_bytes, 0x00020000);
-    const unsigned OOB0 = p.src0_bytes;
-
-    // ---- gather state: this thread stages rows (tid >> 3) + 64*pass of each half-tile, physical chunk tid & 7 ----
-    const int lrow = tid >> 3;                                        // 0..63
-    const int lchunk = ((tid & 7) ^ ((lrow >> 1) & 7)) * 8;           // logical chunk (in bf16) fetched into that slot
-    int aoff[4], ahw[4];                                              // [half*2 + pass]
-    const int HoWo = p.Ho * p.Wo;
-    const int b0 = m0 / HoWo;
-    const int r0 = m0 - b0 * HoWo;
-    const int ho0 = r0 / p.Wo;
-    const int wo0 = r0 - ho0 * p.Wo;
-    const float rcpW = 1.0f / (float)p.Wo, rcpH = 1.0f / (float)p.Ho;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + i * 64 + lrow;
-        const int x = wo0 + i * 64 + lrow;
-        const int qx = (int)(((float)x + 0.5f) * rcpW);
-        const int wo = x - qx * p.Wo;
-        const int y = ho0 + qx;
-        const int qy = (int)(((float)y + 0.5f) * rcpH);
-        const int ho = y - qy * p.Ho;
-        const int b = b0 + qy;
-        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-        aoff[i] = ((b * p.H + hi0) * p.W + wi0) * p.Cin;
-        ahw[i] = (m < p.M) ? ((hi0 << 16) | (wi0 & 0xffff)) : (int)0x80000000;
-    }
-    unsigned boff[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) boff[j] = (unsigned)((n0 + j * 64 + lrow) * p.K + lchunk) * 2u;
-
-    typedef __attribute__((address_space(3))) void *lds_ptr;
-    // K tile t: k = 64 t = tap * Cin + c0
-    auto stage_a = [&](int t, int buf) {
-        const int k = t * BK;
-        const int tap = k / p.Cin, c0 = k - tap * p.Cin;
-        const int u = tap / p.ksize, v = tap - u * p.ksize;
-        const int toff = (u * p.W + v) * p.Cin + lchunk;
-        unsigned char *base = smem + buf * BUF_B + wave * 8 * ROWB;    // wave w fills rows [64*pass + 8w, +8)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int hi = (ahw[i] >> 16) + u, wi = (int)(short)(ahw[i] & 0xffff) + v;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned vo = ok ? (unsigned)(aoff[i] + toff) * 2u : OOB0;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)(base + i * 64 * ROWB), 16, (int)vo, c0 * 2, 0, 0);
-        }
-    };
-    auto stage_b = [&](int t, int buf) {
-        unsigned char *base = smem + buf * BUF_B + 2 * HALF_B + wave * 8 * ROWB;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(base + j * 64 * ROWB), 16, (int)boff[j], t * BK * 2, 0, 0);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int KT = p.K / BK;
-    const int fr = lane & 31, fh = lane >> 5;
-    // fragment addresses: A rows of this wave = half wr, rows 32 i + fr; B rows = half (wc >> 1), rows (wc & 1) * 64 + 32 j + fr
-    const int a_row0 = wr * HALF_B + fr * ROWB;
-    const int b_row0 = 2 * HALF_B + (wc >> 1) * HALF_B + ((wc & 1) * 64 + fr) * ROWB;
-    int foff[4];
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) foff[s_] = ((2 * s_ + fh) ^ ((fr >> 1) & 7)) * 16;
-
-    // prologue: K tile 0 and the weights of K tile 1 (KT >= 2)
-    stage_a(0, 0);
-    stage_b(0, 0);
-    stage_b(1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile 0 (the first 8 loads of this wave) has landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // stagger: the waves of the second M half (one per SIMD, next to a wave of the first half) run one barrier behind,
-    // so on every SIMD one wave issues its MFMAs while the other issues its LDS reads / DMA loads
-    if (wr == 1) __builtin_amdgcn_s_barrier();
-
-    bf16x8 fa[2][4], fb[2][4];                           // [m block within the phase][k step], [n block][k step]
-    auto rd_a = [&](int buf, int ib) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_)
-                fa[i][s_] = *reinterpret_cast<const bf16x8 *>(smem + buf * BUF_B + a_row0 + (ib + i) * 32 * ROWB + foff[s_]);
-    };
-    auto rd_b = [&](int buf, int j) {
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_)
-            fb[j][s_] = *reinterpret_cast<const bf16x8 *>(smem + buf * BUF_B + b_row0 + j * 32 * ROWB + foff[s_]);
-    };
-    auto mma = [&](int ib, int j) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                acc[ib + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s_], fb[j][s_], acc[ib + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto bar = [&]() {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-
-    for (int t = 0; t < KT; ++t) {
-        const int buf = t & 1;
-        // P0: activations of K tile t+1 go to the other buffer (its A half-tiles were last read two phases ago)
-        rd_b(buf, 0);
-        rd_a(buf, 0);
-        if (t + 1 < KT) stage_a(t + 1, buf ^ 1);
-        bar();
-        mma(0, 0);
-        bar();
-        // P1
-        rd_b(buf, 1);
-        bar();
-        mma(0, 1);
-        bar();
-        // P2
-        rd_a(buf, 2);
-        bar();
-        mma(2, 1);
-        bar();
-        // P3: everything this wave has in flight (A of tile t+1 from P0, B of tile t+1 from the previous P3) must land
-        // before the next P0 reads it, one barrier pair later; then the weights of K tile t+2 go to THIS buffer (its B
-        // half-tiles were last read in P1 -- two phases ago, which also covers the staggered half)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (t + 2 < KT) stage_b(t + 2, buf);
-        bar();
-        mma(2, 0);
-        bar();
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();           // the first half catches the staggered half's extra barrier
-
-    // ---- epilogue through LDS (as conv_bf16_mfma): per pass the i-th 32-row block of every wave ----------------
-    constexpr int EROWS = WR * 32;
-    constexpr int PPR = BN / 8;
-    constexpr int NPC = (EROWS * PPR + NT - 1) / NT;
-    float *C = reinterpret_cast<float *>(smem);
-    unsigned short *dstb = static_cast<unsigned short *>(p.dst);
-    const unsigned short *res = static_cast<const unsigned short *>(p.residual);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        u32x4 rr[NPC];
-        if (res) {
-#pragma unroll
-            for (int it = 0; it < NPC; ++it) {
-                const int pc = tid + it * NT;
-                const int r = pc / PPR, ch = (pc - r * PPR) * 8;
-                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31);
-                rr[it] = (pc < EROWS * PPR && m < p.M) ? *reinterpret_cast<const u32x4 *>(res + (size_t)m * p.Cout + n0 + ch)
-                                                       : u32x4{0u, 0u, 0u, 0u};
-            }
-        }
-        __syncthreads();   // previous pass (or the K loop's last fragment reads) done
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = (wc * TN + j) * 32 + fr;
-            const float sc = p.scale[n0 + nl], sh = p.shift[n0 + nl];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] * sc + sh;
-                if (p.leaky) v = fmaxf(v, 0.1f * v);
-                C[(wr * 32 + 4 * fh + (e & 3) + 8 * (e >> 2)) * CROW + nl] = v;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < NPC; ++it) {
-            const int pc = tid + it * NT;
-            const int r = pc / PPR, ch = (pc - r * PPR) * 8;
-            const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31);
-            if (pc >= EROWS * PPR || m >= p.M) continue;
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(C + r * CROW + ch);
-            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(C + r * CROW + ch + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            if (res) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[2 * k] = __uint_as_float(rr[it][k] << 16) + v[2 * k];
-                    v[2 * k + 1] = __uint_as_float(rr[it][k] & 0xffff0000u) + v[2 * k + 1];
-                }
-            }
-            u32x4 out;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) out[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
-            *reinterpret_cast<u32x4 *>(dstb + (size_t)m * p.Cout + n0 + ch) = out;
-        }
-    }
-}
-
-static hipError_t launch_conv_bf16_pipe(const ConvArgs &a, bool out_f32, hipStream_t s)
-{
-    if (out_f32 || a.src1 || a.Cin % 64 || a.CoutPad % 256 || a.Cout != a.CoutPad || a.K / 64 < 2) return hipErrorInvalidValue;
-    const int tilesM = (a.M + 255) / 256, tilesN = a.CoutPad / 256;
-    const size_t lds = 2 * 4 * 128 * 128;   // 128 KB (the epilogue tile, 64 x 260 floats, fits inside)
-    static LdsAttrOnce attr;
-    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv_bf16_pipe), (int)lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv_bf16_pipe, dim3(tilesM * tilesN), dim3(512), lds, s, a);
-    return hipGetLastError();
-}
-#endif   // Y3_EXPERIMENTAL
-
 // tile table of the bf16 kernel: {BM, BN, waves, BK}
 static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 32, 4, 64},
@@ -689,7 +435,7 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {64, 128, 4, 64}, {128, 256, 8, 64},  // 8..13: LDS-DMA
     {256, 256, 8, 64}, {256, 128, 4, 64}, {128, 256, 4, 64},  // 14..16: LDS-DMA, 128x64 / 64x128 wave tiles
     {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64},   // 17..19: LDS-DMA, 16 waves (64x64 / 64x32 / 32x64 wave tiles)
-    {256, 256, 8, 64},                                            // 20: pipelined K loop (counted vmcnt, raw barriers)
+    {0, 0, 0, 64},                                                // 20: retired id (the pipelined tile of round 2)
     {128, 256, 8, 32}, {256, 128, 8, 32}, {128, 128, 4, 32},      // 21..23: LDS-DMA with BK = 32, several workgroups per CU
     {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64}, {128, 128, 4, 64}, {128, 64, 4, 64}, {64, 128, 4, 64},  // 24..29: 16x16x32 MFMAs
     {128, 64, 4, 32}, {64, 64, 4, 32},                            // 30, 31: LDS-DMA with BK = 32 for the Cin = 32 / Cout = 64 layer
@@ -705,15 +451,7 @@ extern "C" int y3_dbg_copy_stamps(unsigned long long *dst, int n_words)
 
 TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < BF16_TILE_COUNT) ? tile : 0]; }
 
-bool conv_bf16_tile_built(int tile)
-{
-    if (tile < 0 || tile >= BF16_TILE_COUNT) return false;
-#ifdef Y3_EXPERIMENTAL
-    return true;
-#else
-    return tile != 20;   // the pipelined tile lost to tile 17: experimental builds only
-#endif
-}
+bool conv_bf16_tile_built(int tile) { return tile >= 0 && tile < BF16_TILE_COUNT && kTilesBf16[tile].bm > 0; }
 
 template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false, int MINW = 1, bool M16 = false>
 static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
@@ -741,18 +479,9 @@ static hipError_t launch_tb(const ConvArgs &a, bool out_f32, hipStream_t s)
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
 {
-    if (tile < 0 || tile >= BF16_TILE_COUNT) return hipErrorInvalidValue;
+    if (!conv_bf16_tile_built(tile)) return hipErrorInvalidValue;
     const TileInfo t = kTilesBf16[tile];
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
-    if (tile == 20) {   // the pipelined tile covers bf16-output convs with full 256-wide channel tiles; others run tile 17
-#ifdef Y3_EXPERIMENTAL
-        if (!(out_f32 || a.src1 || a.Cin % 64 || a.CoutPad % 256 || a.Cout != a.CoutPad || a.K / 64 < 2))
-            return launch_conv_bf16_pipe(a, out_f32, s);
-        tile = 17;
-#else
-        return hipErrorInvalidValue;   // measured slower than tile 17 (profiles/r02_tile_sweep_bf16_pipelined_*): experimental builds only
-#endif
-    }
     switch (tile) {
         case 0: return launch_tb<2, 2, 2, 2, 64>(a, out_f32, s);
         case 1: return launch_tb<2, 2, 4, 2, 64>(a, out_f32, s);

@@ -37,25 +37,14 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned v
     return __builtin_bit_cast(f32x4, v);
 }
 
-// PROBE != 0 builds timing-only ablations of the main loop (wrong results; tools/tune_tiles.py --probe):
-//   1: LDS fragment reads + MFMA only   2: 1 + the two barriers   3: 2 + global fetches (never staged)
-//   4: MFMA + barriers only (fragments read from LDS once, before the loop)
 // DMA != 0: operand tiles are filled by direct-to-LDS buffer loads (no VGPR round trip, no ds_write): measured with
 // tools/mfma_probe.hip, a 16-B load to VGPRs costs the SIMD ~8-16 cycles of matrix-pipe time and a ds_write_b128 ~13,
 // an LDS-DMA load ~4.  LDS rows are then unpadded 128 B (a wave instruction writes 8 whole rows) and bank conflicts
 // are avoided by an XOR swizzle of the 16-B chunk index applied on the SOURCE address and on the fragment reads.
 //
-// SK != 0: persistent "stream-K" schedule.  The launch has as many workgroups as the chip holds at once; the
-// (tile, K-tile) iteration space, tile-major, is cut into equal contiguous shares, so every workgroup runs the same
-// number of MFMAs and the launch ends everywhere at once instead of draining tile by tile (a conv launch is only 2.6-5.3
-// "rounds" of workgroups deep; profiles/r02_batch_scaling_f32.txt prices the drain at ~12 us per launch = 3 % of the step).
-// A tile whose K range is cut is summed through fp32 slabs in the workspace: every contributor writes its partial
-// accumulators write-through (sc1), drains, and takes a ticket on the tile's counter; whoever draws the last ticket
-// reads ALL slabs back (its own too) in contributor order -- so the sum does not depend on who arrives last -- and
-// runs the epilogue.  Nobody waits for anybody (no spinning, no residency assumption).  Protocol:
-// cdna_hip_programming.md section 5 (split-K slab reducer) / Guideline 16.
-// RESPF != 0 (tiles 41..45, convs with a shortcut operand only): the residual values of the tile are requested at the
-// top of the LAST K iteration instead of after it, so their latency runs under that iteration's 32 MFMAs per wave.
+// Removed in round 4 (records under profiles/r01_*, r02_*, code in the history): the timing-only PROBE ablations, the
+// persistent stream-K schedule (neutral on 3x3, -10 % on 1x1 layers: profiles/r02_tile_sweep_f32_streamk_b64_s416.txt) and the
+// residual-prefetch tiles (conv stack -0.3 %: profiles/r02_residual_prefetch_ab.txt).
 #ifdef Y3_PHASE_STAMPS
 // Diagnostic build only (csrc/build.py --variant ... -DY3_PHASE_STAMPS, tools/phase_stamps.py --dtype f32): thread 0 of every workgroup
 // (up to 32768) of the launches whose K equals y3_dbg32_sel_k stores s_memrealtime (100 MHz) at kernel entry, before the first fetch,
@@ -67,7 +56,7 @@ __device__ int y3_dbg32_sel_k = -1;
 #define Y3_STAMP32(k) do { } while (0)
 #endif
 
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0, int RESPF = 0>
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int MINW = 1, int DMA = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvArgs p)
 {
     Y3_STAMP32(0);
@@ -77,7 +66,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         y3_dbg32_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
     }
 #endif
-    static_assert(!(RESPF && SK), "residual prefetch is built for the classic schedule only");
     constexpr int LDS_ROW = DMA ? BK : BK + 4;  // floats per LDS row
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
@@ -108,21 +96,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int tilesN = p.CoutPad / BN;
     const int KT = p.K / BK;
-    // stream-K: workgroup l owns iterations [l*q + min(l,r), +q (+1 if l < r)) of the tile-major (tile, K-tile) space
-    int sk_q = 0, sk_r = 0, it = 0, it_end = 0;
-    if (SK) {
-        const int total = p.sk_tiles * KT;
-        sk_q = total / nwg;
-        sk_r = total - sk_q * nwg;
-        it = logical * sk_q + min(logical, sk_r);
-        it_end = it + sk_q + (logical < sk_r ? 1 : 0);
-    }
-    auto sk_begin_of = [&](int l) { return l * sk_q + min(l, sk_r); };
-    auto sk_owner = [&](int i) {
-        const int cut = sk_r * (sk_q + 1);
-        return i < cut ? i / (sk_q + 1) : sk_r + (i - cut) / sk_q;
-    };
-    bool first_segment = true;
     const __amdgpu_buffer_rsrc_t rs0 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.src0), 0, p.src0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -137,17 +110,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         const_cast<void *>(p.residual ? p.residual : p.dst), 0, p.dst_bytes, 0x00020000);
     const int fr = lane & 31, fh = lane >> 5;
 
-  int seg_k0 = 0, seg_k1 = KT;
-  do {   // one pass per segment = (tile, K-tile range); the classic schedule makes exactly one pass
-    int tile = logical;
-    if (SK) {
-        tile = it / KT;
-        seg_k0 = it - tile * KT;
-        seg_k1 = min(KT, seg_k0 + (it_end - it));
-        if (!first_segment) __syncthreads();   // slower waves may still read the previous segment's LDS tiles / flag
-    }
+    const int tile = logical;
     int mt = tile / tilesN, nt = tile - mt * tilesN;
-    if (!SK && p.xcd_gn > 0) {
+    if (p.xcd_gn > 0) {
         // XCD-blocked order (launch_k sizes the grid for it): the 8 XCDs form a (8/gn) x gn grid over the tile matrix;
         // XCD (xm, xn) owns M-tiles [xm*tilesM/gm, (xm+1)*tilesM/gm) x N-tiles [xn*tilesN/gn, +tilesN/gn), N fastest.
         // With gn > 1 an XCD streams only 1/gn of the weight matrix through its 4 MB L2 (the 256->512 and 512->1024
@@ -219,10 +184,10 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     // packed [n][tap * Cin + c]; only the soffsets change).  The 9 reads of a pixel's CK channels (one per tap) then fall into
     // 9 * CK / 32 consecutive K tiles instead of being Cin / 32 tiles apart, so the tap re-reads hit in L2: with the classic
     // order a 512 -> 1024 @13 launch fetched 1.5-1.9 GB from beyond L2 for 85 MB of operands (tools/traffic_per_layer.py).
-    const int CK = (!CONCAT && !SK && p.k_chunk > 0 && p.k_chunk < p.Cin) ? p.k_chunk : p.Cin;
-    int kglob = seg_k0 * BK;  // k index of the next tile to fetch
-    int tap = CONCAT ? 0 : kglob / p.Cin;
-    int c0 = kglob - tap * p.Cin;
+    const int CK = (!CONCAT && p.k_chunk > 0 && p.k_chunk < p.Cin) ? p.k_chunk : p.Cin;
+    int kglob = 0;  // k index of the next tile to fetch
+    int tap = 0;
+    int c0 = 0;
     int cend = CK;            // end of the current channel chunk (classic order: Cin)
     const int taps = p.ksize * p.ksize;
     unsigned avoff[AP];                  // voffset of this lane's piece for the current tap (or OOB0)
@@ -293,7 +258,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         c0 += BK;
         if (c0 == cend) {
             ++tap;
-            if (!CONCAT && !SK && tap == taps && cend != p.Cin) {   // chunked order: next channel chunk, first tap again
+            if (!CONCAT && tap == taps && cend != p.Cin) {   // chunked order: next channel chunk, first tap again
                 tap = 0;
                 cend += CK;
             }
@@ -321,7 +286,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
         c0 += BK;
         if (c0 == cend) {
             ++tap;
-            if (!CONCAT && !SK && tap == taps && cend != p.Cin) {   // chunked order: next channel chunk, first tap again
+            if (!CONCAT && tap == taps && cend != p.Cin) {   // chunked order: next channel chunk, first tap again
                 tap = 0;
                 cend += CK;
             }
@@ -364,66 +329,26 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
     for (int q = 0; q < 4; ++q) foff[q] = DMA ? ((((2 * q + fh) ^ ((fr >> 1) & 7)) * 4)) : q * 8;
 
-    // epilogue geometry (needed early by the residual prefetch)
+    // epilogue geometry
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.Cout);
     const int row_bytes = p.Cout * 4;
-    float rres[RESPF ? TM : 1][RESPF ? TN : 1][16];
-    auto load_res = [&]() {
-#pragma unroll
-        for (int j = 0; j < (RESPF ? TN : 0); ++j) {
-            const int n = n0 + (wc * TN + j) * 32 + fr;
-#pragma unroll
-            for (int i = 0; i < (RESPF ? TM : 0); ++i) {
-                const int mbase = m0 + (wr * TM + i) * 32 + 4 * fh;
-                const unsigned vbase = (unsigned)(mbase * p.Cout + n) * 4u;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int dm = (e & 3) + 8 * (e >> 2);
-                    unsigned u;
-                    if (interior) {
-                        u = __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)vbase, dm * row_bytes, 0);
-                    } else {
-                        const unsigned off = (n < p.Cout && mbase + dm < p.M) ? (unsigned)((mbase + dm) * p.Cout + n) * 4u : p.dst_bytes;
-                        u = __builtin_amdgcn_raw_buffer_load_b32(rsr, (int)off, 0, 0);
-                    }
-                    rres[i][j][e] = __builtin_bit_cast(float, u);
-                }
-            }
-        }
-    };
 
-    f32x4 pfa[TM], pfb[TN];
-    if (PROBE == 4) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) pfa[i] = *reinterpret_cast<const f32x4 *>(smem + a_frag + i * 32 * LDS_ROW);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) pfb[j] = *reinterpret_cast<const f32x4 *>(smem + b_frag + j * 32 * LDS_ROW);
-    }
-    for (int kt = seg_k0; kt < seg_k1; ++kt) {
-        const int cur = (STAGES == 2) ? ((kt - seg_k0) & 1) : 0;
-        if (RESPF && kt == seg_k1 - 1) load_res();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = (STAGES == 2) ? (kt & 1) : 0;
         if (DMA && STAGES == 2) {
-            if (kt + 1 < seg_k1) fetch_dma(cur ^ 1);   // every wave passed the barrier that ended tile kt-1: buf cur^1 is free
-        } else if (DMA) {
-        } else if (PROBE == 0 || PROBE == 3) {
-            if (kt + 1 < seg_k1) fetch();
+            if (kt + 1 < KT) fetch_dma(cur ^ 1);   // every wave passed the barrier that ended tile kt-1: buf cur^1 is free
+        } else if (!DMA) {
+            if (kt + 1 < KT) fetch();
         }
         const float *sa = smem + cur * STAGE + a_frag;
         const float *sb = smem + cur * STAGE + b_frag;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 fa[TM], fb[TN];
-            if (PROBE == 4) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = pfa[i];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = pfb[j];
-            } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(sa + i * 32 * LDS_ROW + foff[q]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(sb + j * 32 * LDS_ROW + foff[q]);
-            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -437,27 +362,16 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt+1 has landed (issued a whole K tile ago)
             __syncthreads();
         } else if (DMA) {
-            if (kt + 1 < seg_k1) {
+            if (kt + 1 < KT) {
                 __syncthreads();   // every wave is done reading the single buffer
                 fetch_dma(0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
-        } else if (PROBE != 0) {
-            if (PROBE >= 2) {
-                __syncthreads();
-                __syncthreads();
-            }
-            if (PROBE == 3) {
-#pragma unroll
-                for (int i = 0; i < AP; ++i) asm volatile("" ::"v"(ra[i]));
-#pragma unroll
-                for (int j = 0; j < BP; ++j) asm volatile("" ::"v"(rb[j]));
-            }
         } else if (STAGES == 2) {
-            if (kt + 1 < seg_k1) stage(cur ^ 1);
+            if (kt + 1 < KT) stage(cur ^ 1);
             __syncthreads();
-        } else if (kt + 1 < seg_k1) {
+        } else if (kt + 1 < KT) {
             __syncthreads();  // every wave is done reading the tile
             stage(0);
             __syncthreads();
@@ -465,63 +379,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     }
 
     Y3_STAMP32(3);
-    // ---- stream-K: a cut tile is completed by whoever contributes last -----------------------------------
-    if (SK && (seg_k0 != 0 || seg_k1 != KT)) {
-        constexpr unsigned SLAB = BM * BN * 4;                    // bytes of one partial tile: [TM*TN*4][NT] x 16 B
-        const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(p.sk_ws, 0, p.sk_ws_bytes, 0x00020000);
-        const int t_begin = tile * KT;
-        const int c_first = sk_owner(t_begin), c_last = sk_owner(t_begin + KT - 1);
-        // a workgroup has at most two cut segments: slot 0 = the one that starts its range, slot 1 = the other
-        const unsigned my_off = (unsigned)(2 * logical + (it == sk_begin_of(logical) ? 0 : 1)) * SLAB + (unsigned)tid * 16u;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    // (whole-vector bit casts: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0)
-                    const f32x4 f = {acc[i][j][e4 * 4 + 0], acc[i][j][e4 * 4 + 1], acc[i][j][e4 * 4 + 2], acc[i][j][e4 * 4 + 3]};
-                    const u32x4 v = __builtin_bit_cast(u32x4, f);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rsk, (int)my_off, ((i * TN + j) * 4 + e4) * NT * 16, 16);  // aux 16 = sc1: write-through
-                }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the ticket
-        __syncthreads();
-        int *flag = reinterpret_cast<int *>(smem);                 // the operand tiles are dead here
-        if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(p.sk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int is_last = (old == c_last - c_first) ? 1 : 0;
-            if (is_last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(p.sk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-            }
-            *flag = is_last;
-        }
-        __syncthreads();
-        if (*flag == 0) continue;                                  // somebody else finishes this tile
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-        for (int c = c_first; c <= c_last; ++c) {                  // fixed order: the sum is independent of arrival order
-            const int cb = sk_begin_of(c);
-            const unsigned off = (unsigned)(2 * c + (max(cb, t_begin) == cb ? 0 : 1)) * SLAB + (unsigned)tid * 16u;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsk, (int)off, ((i * TN + j) * 4 + e4) * NT * 16, 16);  // sc1: past this CU's L1
-                        const f32x4 f = __builtin_bit_cast(f32x4, v);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[i][j][e4 * 4 + e] += f[e];
-                    }
-        }
-    }
-
     // ---- epilogue ----------------------------------------------------------------------------
     // accumulator element e of lane l: column (n) = l & 31, row (m) = (e & 3) + 8*(e >> 2) + 4*(l >> 5).
     // Straight-line: out-of-tile elements get a voffset == num_records, which the buffer bounds check
@@ -551,10 +408,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                     }
                 }
                 float r[16];
-                if (RES && RESPF) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) r[e] = rres[RESPF ? i : 0][RESPF ? j : 0][e];
-                } else if (RES) {
+                if (RES) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int so = ((e & 3) + 8 * (e >> 2)) * row_bytes;
@@ -592,37 +446,30 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     auto emit2 = [&](auto leaky_tag, auto res_tag) {
         if (interior) emit(leaky_tag, res_tag, T_{}); else emit(leaky_tag, res_tag, F_{});
     };
-    if (RESPF) {                       // built for residual convs only (launch_conv_f32 guarantees p.residual)
-        if (p.leaky) emit2(T_{}, T_{}); else emit2(F_{}, T_{});
-    } else if (p.residual) {
+    if (p.residual) {
         if (p.leaky) emit2(T_{}, T_{}); else emit2(F_{}, T_{});
     } else {
         if (p.leaky) emit2(T_{}, F_{}); else emit2(F_{}, F_{});
     }
     Y3_STAMP32(4);   // thread 0 = wave 0: its own stores issued (not yet retired)
-  } while (SK && (it += seg_k1 - seg_k0, first_segment = false, it < it_end));
     if (p.clk_stamps != nullptr && blockIdx.x == (gridDim.x >> 1) && tid == 0) {
         p.clk_stamps[2] = __builtin_amdgcn_s_memtime();
         p.clk_stamps[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
-// tile table: {BM, BN, waves, LDS stages}; ids are stable (tuning files refer to them)
+// tile table: {BM, BN, waves, LDS stages}; ids are stable (tuning files refer to them).  Ids 20..22 and 25 were the
+// timing-only probes of rounds 1-2 (removed in round 4; the ids stay reserved), 33..45 the stream-K / residual-prefetch tiles.
 static const TileInfo kTiles[TILE_COUNT] = {
     {128, 128, 4, 2}, {256, 64, 4, 2}, {256, 32, 4, 2}, {128, 64, 4, 2}, {64, 128, 4, 2}, {64, 64, 4, 2},
     {128, 128, 4, 1}, {256, 64, 4, 1}, {256, 32, 4, 1}, {128, 64, 4, 1}, {64, 128, 4, 1}, {64, 64, 4, 1},
     {128, 128, 8, 1}, {128, 128, 8, 2}, {128, 128, 16, 1}, {128, 128, 16, 2},
     {256, 128, 16, 1}, {128, 64, 8, 1}, {256, 64, 8, 1}, {128, 64, 8, 2},
-    {64, 128, 4, 1}, {64, 128, 4, 1}, {64, 128, 4, 1},  // timing-only probes of tile 10 (wrong results)
+    {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},            // 20..22: retired ids
     {128, 128, 4, 1}, {128, 128, 4, 1},                  // 128x128 with the register budget of 3 / 4 waves per SIMD
-    {64, 128, 4, 1},                                     // probe 4
+    {0, 0, 0, 0},                                        // 25: retired id
     {64, 128, 4, 2}, {64, 64, 4, 2}, {128, 128, 4, 2}, {128, 64, 4, 2}, {256, 32, 4, 2},  // 26..30: LDS-DMA loads
     {64, 128, 4, 1}, {64, 64, 4, 1},                     // 31, 32: LDS-DMA, single stage
-    // 33..40: stream-K schedule of tiles 10, 11, 9, 17, 26, 27, 31, 32
-    {64, 128, 4, 1, 1}, {64, 64, 4, 1, 1}, {128, 64, 4, 1, 1}, {128, 64, 8, 1, 1},
-    {64, 128, 4, 2, 1}, {64, 64, 4, 2, 1}, {64, 128, 4, 1, 1}, {64, 64, 4, 1, 1},
-    // 41..45: residual prefetch variants of tiles 10, 31, 27, 11, 26 (convs with a shortcut operand only)
-    {64, 128, 4, 1}, {64, 128, 4, 1}, {64, 64, 4, 2}, {64, 64, 4, 1}, {64, 128, 4, 2},
 };
 
 #ifdef Y3_PHASE_STAMPS
@@ -635,60 +482,25 @@ extern "C" int y3_dbg32_copy_stamps(unsigned long long *dst, int n_words)
 
 TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUNT) ? tile : 0]; }
 
-// Tiles 20..22, 25 (timing probes), 33..40 (stream-K) and 41..45 (residual prefetch) were measured
-// and lost (A/B records under profiles/r02_*): no tuning table or heuristic selects them, so the
-// default library does not carry their code.  csrc/build.py --experimental builds them (-DY3_EXPERIMENTAL).
-bool conv_tile_built(int tile)
-{
-    if (tile < 0 || tile >= TILE_COUNT) return false;
-#ifdef Y3_EXPERIMENTAL
-    return true;
-#else
-    return tile < 20 || tile == 23 || tile == 24 || (tile >= 26 && tile <= 32);
-#endif
-}
+bool conv_tile_built(int tile) { return tile >= 0 && tile < TILE_COUNT && kTiles[tile].bm > 0; }
 
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int PROBE = 0, int MINW = 1, int DMA = 0, int SK = 0, int RESPF = 0>
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int MINW = 1, int DMA = 0>
 static hipError_t launch_k(const ConvArgs &a_in, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     ConvArgs a = a_in;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
     const size_t lds = STAGES * (size_t)(BM + BN) * (DMA ? BK : LDS_ROW_PADDED) * sizeof(float);
-    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, PROBE, MINW, DMA, SK, RESPF>;
+    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, MINW, DMA>;
     static LdsAttrOnce attr;  // per instantiation
     if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
     int grid = tilesM * tilesN;
-    if (!SK && a.xcd_gn > 0) {
+    if (a.xcd_gn > 0) {
         if (8 % a.xcd_gn || tilesN % a.xcd_gn) return hipErrorInvalidValue;
         const int gm = 8 / a.xcd_gn;
         int rows = 0;                                           // largest M block
         for (int xm = 0; xm < gm; ++xm) rows = std::max(rows, (xm + 1) * tilesM / gm - xm * tilesM / gm);
         grid = 8 * rows * (tilesN / a.xcd_gn);
-    }
-    if (SK) {
-        // as many workgroups as are resident at once (occupancy x CUs, per device), never more than there are iterations
-        static int resident[64] = {0};
-        int dev = 0;
-        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        if (!resident[dev]) {
-            int occ = 0, cus = 0;
-            if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 64 * WR * WC, lds); e != hipSuccess) return e;
-            if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
-            if (occ < 1 || cus < 1) return hipErrorInvalidValue;
-            resident[dev] = occ * cus;
-        }
-        const long long total = (long long)grid * (a.K / BK);
-        a.sk_tiles = grid;
-        int g = resident[dev];
-        if (a.sk_grid_override > 0) g = a.sk_grid_override;
-        if ((long long)g > total) g = (int)total;
-        const long long slab = (long long)BM * BN * 4;
-        if (!a.sk_ws || !a.sk_cnt || a.sk_tiles > a.sk_cnt_cap || total > 0x7fffffffLL) return hipErrorInvalidValue;
-        if (2LL * g * slab > (long long)a.sk_ws_bytes) g = (int)((long long)a.sk_ws_bytes / (2 * slab));
-        if (g < 1) return hipErrorInvalidValue;
-        grid = g;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
@@ -701,13 +513,13 @@ static hipError_t launch_t(const ConvArgs &a, int stages, hipStream_t s)
     // 32x64 wave tile stay in architectural VGPRs and the epilogue needs no v_accvgpr_read (nor the prologue 32-64
     // v_accvgpr_write: with the SIMD full of 64-cycle MFMAs every vector instruction outside the K loop waits ~one MFMA for
     // its issue slot, profiles/r03_ab_f32_prologue.txt).  The LDS-DMA tiles 26, 27, 31, 32 and the 64x64 tiles pass 4 as well.
-    if (a.src1) return stages == 2 ? launch_k<TM, TN, WR, WC, true, 2>(a, s) : launch_k<TM, TN, WR, WC, true, 1, 0, MINW1>(a, s);
-    return stages == 2 ? launch_k<TM, TN, WR, WC, false, 2>(a, s) : launch_k<TM, TN, WR, WC, false, 1, 0, MINW1>(a, s);
+    if (a.src1) return stages == 2 ? launch_k<TM, TN, WR, WC, true, 2>(a, s) : launch_k<TM, TN, WR, WC, true, 1, MINW1>(a, s);
+    return stages == 2 ? launch_k<TM, TN, WR, WC, false, 2>(a, s) : launch_k<TM, TN, WR, WC, false, 1, MINW1>(a, s);
 }
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
 {
-    if (tile < 0 || tile >= TILE_COUNT) return hipErrorInvalidValue;
+    if (!conv_tile_built(tile)) return hipErrorInvalidValue;
     const int stages = kTiles[tile].stages;
     switch (tile) {
         case 0: case 6: return launch_t<2, 2, 2, 2>(a, stages, s);    // 128x128, 4 waves
@@ -721,39 +533,16 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 16: return launch_t<2, 1, 4, 4>(a, stages, s);           // 256x128, 16 waves
         case 17: case 19: return launch_t<1, 1, 4, 2>(a, stages, s);  // 128x64, 8 waves
         case 18: return launch_t<2, 1, 4, 2>(a, stages, s);           // 256x64, 8 waves
-#ifdef Y3_EXPERIMENTAL
-        case 20: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 1>(a, s);  // probes (64x128)
-        case 21: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 2>(a, s);
-        case 22: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 3>(a, s);
-        case 25: return a.src1 ? hipErrorInvalidValue : launch_k<1, 2, 2, 2, false, 1, 4>(a, s);
-#endif
         // direct-to-LDS operand loads, double buffered
-        case 26: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 0, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 0, 4, 1>(a, s);  // 64x128
-        case 27: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 0, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 0, 4, 1>(a, s);  // 64x64
-        case 28: return a.src1 ? launch_k<2, 2, 2, 2, true, 2, 0, 1, 1>(a, s) : launch_k<2, 2, 2, 2, false, 2, 0, 1, 1>(a, s);  // 128x128
-        case 29: return a.src1 ? launch_k<1, 2, 4, 1, true, 2, 0, 1, 1>(a, s) : launch_k<1, 2, 4, 1, false, 2, 0, 1, 1>(a, s);  // 128x64
-        case 30: return a.src1 ? launch_k<2, 1, 4, 1, true, 2, 0, 1, 1>(a, s) : launch_k<2, 1, 4, 1, false, 2, 0, 1, 1>(a, s);  // 256x32
-        case 31: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 4, 1>(a, s);  // 64x128, 1 stage
-        case 32: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 4, 1>(a, s);  // 64x64, 1 stage
-#ifdef Y3_EXPERIMENTAL
-        // stream-K schedule (33..40 = tiles 10, 11, 9, 17, 26, 27, 31, 32)
-        case 33: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 4, 0, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 4, 0, 1>(a, s);
-        case 34: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 0, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 0, 1>(a, s);
-        case 35: return a.src1 ? launch_k<1, 2, 4, 1, true, 1, 0, 4, 0, 1>(a, s) : launch_k<1, 2, 4, 1, false, 1, 0, 4, 0, 1>(a, s);
-        case 36: return a.src1 ? launch_k<1, 1, 4, 2, true, 1, 0, 1, 0, 1>(a, s) : launch_k<1, 1, 4, 2, false, 1, 0, 1, 0, 1>(a, s);
-        case 37: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 0, 1, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 0, 1, 1, 1>(a, s);
-        case 38: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 0, 1, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 0, 1, 1, 1>(a, s);
-        case 39: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 0, 1, 1, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 0, 1, 1, 1>(a, s);
-        case 40: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 0, 1, 1, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 0, 1, 1, 1>(a, s);
-        // residual prefetch (3x3 convs with a shortcut operand; anything else runs the base tile)
-        case 41: return (a.residual && !a.src1) ? launch_k<1, 2, 2, 2, false, 1, 0, 4, 0, 0, 1>(a, s) : launch_conv_f32(a, 10, s);
-        case 42: return (a.residual && !a.src1) ? launch_k<1, 2, 2, 2, false, 1, 0, 1, 1, 0, 1>(a, s) : launch_conv_f32(a, 31, s);
-        case 43: return (a.residual && !a.src1) ? launch_k<1, 1, 2, 2, false, 2, 0, 1, 1, 0, 1>(a, s) : launch_conv_f32(a, 27, s);
-        case 44: return (a.residual && !a.src1) ? launch_k<1, 1, 2, 2, false, 1, 0, 1, 0, 0, 1>(a, s) : launch_conv_f32(a, 11, s);
-        case 45: return (a.residual && !a.src1) ? launch_k<1, 2, 2, 2, false, 2, 0, 1, 1, 0, 1>(a, s) : launch_conv_f32(a, 26, s);
-#endif
-        case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 3>(a, s);
-        case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 0, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 0, 4>(a, s);
+        case 26: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 4, 1>(a, s);  // 64x128
+        case 27: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 4, 1>(a, s);  // 64x64
+        case 28: return a.src1 ? launch_k<2, 2, 2, 2, true, 2, 1, 1>(a, s) : launch_k<2, 2, 2, 2, false, 2, 1, 1>(a, s);  // 128x128
+        case 29: return a.src1 ? launch_k<1, 2, 4, 1, true, 2, 1, 1>(a, s) : launch_k<1, 2, 4, 1, false, 2, 1, 1>(a, s);  // 128x64
+        case 30: return a.src1 ? launch_k<2, 1, 4, 1, true, 2, 1, 1>(a, s) : launch_k<2, 1, 4, 1, false, 2, 1, 1>(a, s);  // 256x32
+        case 31: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 4, 1>(a, s);  // 64x128, 1 stage
+        case 32: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 4, 1>(a, s);  // 64x64, 1 stage
+        case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 3>(a, s);
+        case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 4>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

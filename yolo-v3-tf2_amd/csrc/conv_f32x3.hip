@@ -93,22 +93,18 @@ __device__ __forceinline__ void join_planes(const u32x4 (&q)[NPL], int k, float 
     }
 }
 
-// VAR: schedule variants and timing probes of the K loop (one kernel body, so that they stay comparable):
+// VAR: schedule variants of the K loop (one kernel body, so that they stay comparable):
 //   V_BURST      the LDS-DMA instructions of the next K tile are issued together at the top of the iteration (default)
 //   V_ILV        ... issued one or two at a time between the MFMA groups of the current tile (measured: no gain)
 //   V_ILV_PINNED ... and pinned there with sched_group_barrier (no gain)
-//   V_PROBE_A1   timing only, WRONG RESULTS: activations fetched for the first tap only
-//   V_PROBE_SK   timing only, WRONG RESULTS: two workgroups per output tile, each running half of the K loop
-//   V_PROBE_NOLD timing only, WRONG RESULTS: no operand fetches after the first K tile (LDS reads + MFMAs + barriers only)
-//   V_PROBE_LDONLY timing only, WRONG RESULTS: operand fetches and barriers only, no LDS reads, no MFMAs
-//   V_PROBE_1ACC timing only, WRONG RESULTS (two planes): all three products into one accumulator set -- the
-//                register budget of a single-accumulator form of the scheme, which makes 256x256 w16 tiles possible
-enum { V_BURST = 0, V_ILV = 1, V_ILV_PINNED = 2, V_PROBE_A1 = 3, V_PROBE_SK = 4, V_PROBE_NOLD = 5, V_PROBE_LDONLY = 6, V_PROBE_1ACC = 7 };
+// (the timing-only probes of round 1 -- A for one tap, split K, no fetches, fetches only, one accumulator set -- were removed in
+// round 4; their records are profiles/r01_probe_*.txt)
+enum { V_BURST = 0, V_ILV = 1, V_ILV_PINNED = 2 };
 template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int VAR = V_BURST>
 __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p)
 {
     static_assert(NPL == 2 || NPL == 3, "two fp16 planes or three bf16 planes");
-    constexpr int NACC = (NPL == 2 && VAR != V_PROBE_1ACC) ? 2 : 1;   // accumulator sets (two-plane scheme: cross terms carry a 2^11 scale)
+    constexpr int NACC = NPL == 2 ? 2 : 1;   // accumulator sets (two-plane scheme: cross terms carry a 2^11 scale)
     constexpr int MPG = NPL == 2 ? 3 : 6;    // MFMAs per (i, j, k-step) group
     constexpr int BM = 32 * TM * WR;
     constexpr int BN = 32 * TN * WC;
@@ -132,8 +128,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     const int wr = wave / WC, wc = wave % WC;
 
     constexpr bool ILV = VAR == V_ILV || VAR == V_ILV_PINNED;
-    const int nwg = VAR == V_PROBE_SK ? (int)gridDim.x >> 1 : (int)gridDim.x;
-    const int bid = VAR == V_PROBE_SK ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
+    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int tilesN = p.CoutPad / BN;
@@ -216,10 +211,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
         for (int pl = 0; pl < NPL; ++pl) {
             unsigned char *sa = smem + buf * STAGE_B + pl * PLANE_B + wave * RPI * ROWB;
             unsigned char *sb = sa + BM * ROWB;
-            if (VAR == V_PROBE_A1 && tap != 0) {
-                // timing probe (results are wrong): activations fetched for the first tap only -- what would a 3x3
-                // conv gain if its A operand came from an LDS-resident halo patch instead of one L2 read per tap?
-            } else if (CONCAT && c0 >= p.C0) {
+            if (CONCAT && c0 >= p.C0) {
 #pragma unroll
                 for (int i = 0; i < AP; ++i)
                     if (i * RP + wave * RPI < BM)
@@ -309,15 +301,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.0f;
 
-    int KT = p.K / BK;
-    if (VAR == V_PROBE_SK) {
-        const int half = blockIdx.x & 1, k0 = half ? KT / 2 : 0;
-        kglob = k0 * BK;
-        tap = kglob / p.Cin;
-        c0 = kglob - tap * p.Cin;
-        if (!CONCAT) set_tap();
-        KT = half ? KT - KT / 2 : KT / 2;     // k tiles of this half; the loop below counts from 0
-    }
+    const int KT = p.K / BK;
     fetch_dma(0);
     if (STAGES == 3 && KT > 1) {
         fetch_dma(1);
@@ -338,14 +322,14 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = (STAGES == 3) ? cur3 : (STAGES == 2) ? (kt & 1) : 0;
         const bool more = kt + 1 < KT;
-        if (STAGES == 2 && !ILV && VAR != V_PROBE_NOLD && more) fetch_dma(cur ^ 1);
+        if (STAGES == 2 && !ILV && more) fetch_dma(cur ^ 1);
         if (STAGES == 3 && kt + 2 < KT) fetch_dma(cur3 == 0 ? 2 : cur3 - 1);   // stage of tile kt-1, free since the last barrier
         constexpr int NP = NPL * (AP + BP);             // DMA instructions per tile
         constexpr int NG = (BK / 16) * TM * TN;         // MFMA groups (MPG MFMAs each) per tile
         int grp = 0;
         const unsigned char *st = smem + cur * STAGE_B;
 #pragma unroll
-        for (int s = 0; s < (VAR == V_PROBE_LDONLY ? 0 : BK / 16); ++s) {
+        for (int s = 0; s < BK / 16; ++s) {
             typedef typename std::conditional<NPL == 3, bf16x8, f16x8>::type frag_t;
             frag_t fa[NPL][TM], fb[NPL][TN];
 #pragma unroll
@@ -507,12 +491,8 @@ static const TileInfo kTilesX3[X3_TILE_COUNT] = {
     {256, 128, 8, 32}, {128, 256, 8, 32}, {128, 128, 4, 32}, {128, 128, 8, 32},   // 20..23: interleaved DMA issue
     {256, 128, 8, 32}, {128, 256, 8, 32},                                         // 24..25: + pinned order
     {256, 128, 16, 32}, {128, 256, 16, 32},                                       // 26..27: 16 waves, 64x32 wave tiles
-    {256, 128, 16, 32}, {128, 128, 8, 32},                                        // 28..29: two-plane timing probes (A fetched for tap 0 only)
+    {0, 0, 0, 32}, {0, 0, 0, 32},                                                 // 28..29: retired ids (timing probes of round 1)
     {128, 128, 8, 32}, {256, 128, 16, 32}, {256, 128, 8, 32}, {128, 256, 16, 32},  // 30..33: three LDS stages
-    {256, 128, 16, 32}, {128, 128, 8, 32}, {256, 128, 8, 32},                      // 34..36: two-plane timing probes (K loop split over two workgroups)
-    {256, 128, 16, 32}, {128, 128, 8, 32}, {256, 128, 8, 32},                      // 37..39: two-plane timing probes (no fetches in the K loop)
-    {128, 64, 4, 32}, {128, 64, 4, 64}, {128, 128, 8, 32},                         // 40..42: two-plane timing probes (fetches only)
-    {256, 256, 16, 32}, {256, 128, 16, 32}, {256, 128, 8, 32},                     // 43..45: two-plane timing probes (one accumulator set)
 };
 
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
@@ -529,7 +509,7 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
     auto k = conv_f32x3_mfma<NPL, TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES, VAR>;
     static LdsAttrOnce attr;  // per instantiation
     if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(tilesM * tilesN * (VAR == V_PROBE_SK ? 2 : 1)), dim3(64 * WR * WC), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }
 
@@ -553,6 +533,7 @@ hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStrea
 {
     if (tile < 0 || tile >= X3_TILE_COUNT) return hipErrorInvalidValue;
     const TileInfo t = kTilesX3[tile];
+    if (t.bm == 0) return hipErrorInvalidValue;   // retired id
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
     switch (tile) {
         case 0: return launch_tx<2, 2, 2, 2, 32>(a, out_f32, s);
@@ -593,6 +574,7 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
 {
     if (tile < 0 || tile >= X3_TILE_COUNT) return hipErrorInvalidValue;
     const TileInfo t = kTilesX3[tile];
+    if (t.bm == 0) return hipErrorInvalidValue;   // retired id
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;
     switch (tile) {
         case 0: return launch_tp<2, 2, 2, 2, 2, 32>(a, out_f32, s);       // 128x128 w4
@@ -607,28 +589,10 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 12: return launch_tp<2, 2, 1, 2, 4, 32>(a, out_f32, s);      // 128x128 w8
         case 26: return launch_tp<2, 2, 1, 4, 4, 32>(a, out_f32, s);      // 256x128 w16
         case 27: return launch_tp<2, 2, 1, 2, 8, 32>(a, out_f32, s);      // 128x256 w16
-#ifdef Y3_EXPERIMENTAL
-        case 28: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_A1>(a, out_f32, s);   // probe: 256x128 w16, A for tap 0 only
-        case 29: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_A1>(a, out_f32, s);   // probe: 128x128 w8, A for tap 0 only
-#endif
         case 30: return launch_tp<2, 2, 1, 2, 4, 32, 3>(a, out_f32, s);      // 128x128 w8, three stages
         case 31: return launch_tp<2, 2, 1, 4, 4, 32, 3>(a, out_f32, s);      // 256x128 w16, three stages
         case 32: return launch_tp<2, 2, 2, 4, 2, 32, 3>(a, out_f32, s);      // 256x128 w8, three stages
         case 33: return launch_tp<2, 2, 1, 2, 8, 32, 3>(a, out_f32, s);      // 128x256 w16, three stages
-#ifdef Y3_EXPERIMENTAL
-        case 34: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 256x128 w16, split K
-        case 35: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 128x128 w8, split K
-        case 36: return launch_tp<2, 2, 2, 4, 2, 32, 2, V_PROBE_SK>(a, out_f32, s);   // probe: 256x128 w8, split K
-        case 37: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_NOLD>(a, out_f32, s);   // probe: 256x128 w16, no fetches in the loop
-        case 38: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_NOLD>(a, out_f32, s);   // probe: 128x128 w8
-        case 39: return launch_tp<2, 2, 2, 4, 2, 32, 2, V_PROBE_NOLD>(a, out_f32, s);   // probe: 256x128 w8
-        case 40: return launch_tp<2, 2, 1, 2, 2, 32, 2, V_PROBE_LDONLY>(a, out_f32, s);   // probe: 128x64 w4 BK32, fetches only
-        case 41: return launch_tp<2, 2, 1, 2, 2, 64, 2, V_PROBE_LDONLY>(a, out_f32, s);   // probe: 128x64 w4 BK64, fetches only
-        case 42: return launch_tp<2, 2, 1, 2, 4, 32, 2, V_PROBE_LDONLY>(a, out_f32, s);   // probe: 128x128 w8 BK32, fetches only
-        case 43: return launch_tp<2, 2, 2, 4, 4, 32, 2, V_PROBE_1ACC>(a, out_f32, s);   // probe: 256x256 w16 (64x64 wave tiles), one accumulator set
-        case 44: return launch_tp<2, 2, 1, 4, 4, 32, 2, V_PROBE_1ACC>(a, out_f32, s);   // probe: 256x128 w16, one accumulator set
-        case 45: return launch_tp<2, 2, 2, 4, 2, 32, 2, V_PROBE_1ACC>(a, out_f32, s);   // probe: 256x128 w8, one accumulator set
-#endif
         default: return hipErrorInvalidValue;
     }
 }
@@ -639,9 +603,6 @@ bool conv_x2_tile_built(int tile)
 {
     switch (tile) {
         case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 30: case 31: case 32: case 33: return true;
-#ifdef Y3_EXPERIMENTAL
-        case 28: case 29: case 34: case 35: case 36: case 37: case 38: case 39: case 40: case 41: case 42: case 43: case 44: case 45: return true;   // timing-only probes
-#endif
         default: return false;
     }
 }

@@ -374,9 +374,10 @@ hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s)
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// bf16 variant (BASELINE config 5): same tiling and phase structure.  conv0 stays in fp32 arithmetic on the fp32 matrix
-// cores (like the stand-alone bf16 first-layer launch: fp32 image, fp32 weights, y = acc*scale + shift, leaky) and its
-// result is rounded to bf16 exactly where the two-launch form stores it -- here into the LDS patch; conv1 runs on
+// bf16 variant (BASELINE config 5): same tiling and phase structure.  conv0 runs on the BF16 matrix cores from split
+// operands (x = hi + lo, products hi*hi + hi*lo + lo*hi with fp32 accumulation: ~2^-16 relative error per product -- close to,
+// but NOT, the fp32 arithmetic of the stand-alone bf16 first-layer launch; see phase 1 below), then y = acc*scale + shift, leaky,
+// and the result is rounded to bf16 exactly where the two-launch form stores it -- here into the LDS patch; conv1 runs on
 // v_mfma_f32_32x32x16_bf16 from LDS (bf16 weights, unscaled; y = acc*scale + shift, leaky, bf16 out).
 // LDS: patch 561 x 64 B (chunk c of pixel (y, x) at c ^ ((x >> 2) & 3)), w1 64 x 576 B (chunk c of a tap's four at
 // c ^ ((n >> 2) & 3)), image patch 7,980 B: 80,748 B -> TWO workgroups per CU, one computing while the other stores.

@@ -56,6 +56,24 @@ namespace {
                         hipGetErrorString(e_));                                                   \
     } while (0)
 
+// Enter the net's device for the duration of a call and give the caller its own current device back on every return path (a
+// process driving several GPUs -- PyTorch with nets on different devices -- must not find its current device changed).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) err = hipSetDevice(dev); else if (err == hipSuccess) prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define Y3_ENTER_DEVICE(net_)                                                                      \
+    DeviceGuard dev_guard_((net_)->device);                                                        \
+    if (dev_guard_.err != hipSuccess) return fail(Y3_ERR_HIP, "hipSetDevice(%d): %s", (net_)->device, hipGetErrorString(dev_guard_.err))
+
 struct ConvSlot {
     y3_conv_desc d{};
     bool loaded = false;
@@ -112,11 +130,6 @@ struct y3_net {
     // y3_net_plan for max_batch images and Y3_MAX_OUTPUT_BOXES rows, so y3_net_detect itself only enqueues work
     void *det_buf = nullptr;
     size_t det_bytes = 0;
-    // stream-K conv tiles (fp32): partial-tile slabs + per-tile ticket counters, one region per lane
-    void *sk_ws = nullptr;
-    int *sk_cnt = nullptr;
-    size_t sk_ws_lane_bytes = 0;
-    int sk_cnt_cap = 0;
     int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 (+ the 1x1 after them) as one kernel when the graph allows it; 2 = conv0 + conv1 only
     bool stem_mode_set = false;    // y3_net_set_stem_fusion was called (the Y3_STEM_MODE tool override then stays out)
     bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
@@ -125,7 +138,6 @@ struct y3_net {
     int clk_conv = -1;                          // ... and which conv (-2: every conv, 8 words each at clk_stamps + 8 conv)
     int xcd_mode = 1;              // y3_net_set_xcd_mode: 0 contiguous tile runs per XCD, 1 XCD-blocked order chosen per conv
     int k_chunk = -1;              // y3_net_set_k_chunk: fp32 3x3 convs walk K chunk-major, this many input channels per chunk; 0 tap-major; -1 per-conv default
-    int sk_grid = 0;               // y3_net_set_sk_grid: > 0 overrides the number of persistent workgroups (tests)
     int cur_batch = 1;             // batch of the forward being enqueued
     hipEvent_t fork_ev = nullptr;
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -145,12 +157,6 @@ void free_plan(y3_net *n)
     if (n->det_buf) (void)hipFree(n->det_buf);
     n->det_buf = nullptr;
     n->det_bytes = 0;
-    if (n->sk_ws) (void)hipFree(n->sk_ws);
-    if (n->sk_cnt) (void)hipFree(n->sk_cnt);
-    n->sk_ws = nullptr;
-    n->sk_cnt = nullptr;
-    n->sk_ws_lane_bytes = 0;
-    n->sk_cnt_cap = 0;
     for (void *p : n->blocks) (void)hipFree(p);
     n->blocks.clear();
     n->tdev.assign(n->tensors.size(), nullptr);
@@ -205,16 +211,6 @@ float f16_to_f32(unsigned short h)
     return (h & 0x8000) ? -v : v;
 }
 
-// Timing-only ablation kernels (wrong results by construction) stay out of reach of the public setters unless the
-// process opts in with Y3_ALLOW_PROBE_TILES=1 (tools/tune_tiles.py --probe does).
-bool probes_allowed()
-{
-    const char *e = getenv("Y3_ALLOW_PROBE_TILES");
-    return e && e[0] == '1';
-}
-bool is_probe_tile_f32(int t) { return t == 20 || t == 21 || t == 22 || t == 25; }
-bool is_probe_tile_x2(int t) { return t == 28 || t == 29 || (t >= 34 && t <= 45); }
-
 int choose_tile_x2(const ConvSlot &c, long long M)
 {
     // widest tile that still gives every CU at least two workgroups
@@ -254,12 +250,22 @@ int choose_tile_x3(const ConvSlot &c, long long M)
     return best;
 }
 
-int choose_tile_bf16(const ConvSlot &c, long long M)
+// M = rows of this call (per lane); M_plan = rows of the planned batch.  The MFMA SHAPE (16x16x32 vs 32x32x16: two K groupings,
+// results differ in the last bits) is decided from plan-time quantities only, so that an image's result does not depend on the
+// batch or lane it runs in (y3_net_set_lanes: "results are unchanged"); the tile SIZE within one shape follows the call.
+int choose_tile_bf16(const ConvSlot &c, long long M, long long M_plan)
 {
-    // large 3x3 convs: the 256x256 tile of 16 waves on 16x16x32 MFMAs once it fills the chip (tile 24 wins every such
-    // signature of the 64- and 128-image tables, tuning/bf16_b*_s416.json)
-    if (c.d.size == 3 && c.d.src1 < 0 && c.d.cin % 64 == 0 && c.cout_pad % 256 == 0 && ((M + 255) / 256) * (c.cout_pad / 256) >= 256)
-        return 24;
+    auto blocks = [&](int t) {
+        y3::TileInfo s = y3::conv_bf16_tile_info(t);
+        return ((M + s.bm - 1) / s.bm) * (c.cout_pad / s.bn);
+    };
+    // large 3x3 convs: the 16x16x32 form once the PLANNED batch fills the chip with 256x256 tiles of 16 waves (tile 24 wins every
+    // such signature of the 64- and 128-image tables, tuning/bf16_b*_s416.json); smaller calls of the same plan take the 128x128 /
+    // 64x128 tiles of the same MFMA shape (27, 29)
+    if (c.d.size == 3 && c.d.src1 < 0 && c.d.cin % 64 == 0 && c.cout_pad % 256 == 0 && ((M_plan + 255) / 256) * (c.cout_pad / 256) >= 256) {
+        if (blocks(24) >= 256) return 24;
+        return blocks(27) >= 512 ? 27 : 29;
+    }
     std::vector<int> cand;
     if (c.d.cin % 64)
         cand = {5, 6};                       // BK = 32 (Cin = 32 layers, Cout = 64)
@@ -271,10 +277,8 @@ int choose_tile_bf16(const ConvSlot &c, long long M)
         cand = {4};
     int best = cand.back();
     for (int t : cand) {
-        y3::TileInfo s = y3::conv_bf16_tile_info(t);
-        if (c.cout_pad % s.bn) continue;
-        long long blocks = ((M + s.bm - 1) / s.bm) * (c.cout_pad / s.bn);
-        if (blocks >= 512) {
+        if (c.cout_pad % y3::conv_bf16_tile_info(t).bn) continue;
+        if (blocks(t) >= 512) {
             best = t;
             break;
         }
@@ -299,7 +303,6 @@ int default_k_chunk(const ConvSlot &c)
 // its workgroups walk the K loop.  0 = not applicable (tile count too small / not divisible).
 int choose_xcd_gn(const ConvSlot &c, const y3::ConvArgs &a, const y3::TileInfo &t)
 {
-    if (t.sk) return 0;
     const int tilesN = a.CoutPad / t.bn;
     const long long tilesM = (a.M + t.bm - 1) / t.bm;
     if (tilesM * tilesN < 64) return 0;
@@ -531,7 +534,7 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
         for (int n = 0; n < d.cout; ++n)
             for (int k = 0; k < K; ++k) pk_scaled[(size_t)n * K + k] *= scale[n];
     }
-    HIP_TRY(hipSetDevice(net->device));
+    Y3_ENTER_DEVICE(net);
     if (!c.w_dev) HIP_TRY(hipMalloc(&c.w_dev, pk.size() * sizeof(float)));
     if (!c.scale_dev) HIP_TRY(hipMalloc(&c.scale_dev, CP64 * sizeof(float)));
     if (!c.shift_dev) HIP_TRY(hipMalloc(&c.shift_dev, CP64 * sizeof(float)));
@@ -590,34 +593,6 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
     return Y3_OK;
 }
 
-// stream-K workspace of a planned fp32 net: 2 slabs per persistent workgroup (<= 2048 of them, <= 32 KB each) and one
-// ticket counter per output tile of the finest stream-K tile (64 x 64), per lane.  Counters are zeroed here
-// (synchronously) and returned to zero by the last contributor of every cut tile.
-static y3_status ensure_sk_workspace(y3_net *net)
-{
-    if (net->sk_ws) return Y3_OK;
-    HIP_TRY(hipSetDevice(net->device));
-    net->sk_ws_lane_bytes = (size_t)2 * 2048 * 32768;
-    long long cap = 1;
-    for (const ConvSlot &c : net->convs) {
-        const long long sp = net->image_size / c.d.out_div;
-        const long long tiles = (((long long)net->max_batch * sp * sp + 63) / 64) * ((c.cout_pad + 63) / 64);
-        if (!c.first_layer && tiles > cap) cap = tiles;
-    }
-    net->sk_cnt_cap = (int)((cap + 3) & ~3LL);
-    hipError_t e = hipMalloc(&net->sk_ws, net->sk_ws_lane_bytes * Y3_MAX_LANES);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&net->sk_cnt), (size_t)net->sk_cnt_cap * 4 * Y3_MAX_LANES);
-    if (e == hipSuccess) e = hipMemset(net->sk_cnt, 0, (size_t)net->sk_cnt_cap * 4 * Y3_MAX_LANES);
-    if (e != hipSuccess) {
-        if (net->sk_ws) (void)hipFree(net->sk_ws);
-        if (net->sk_cnt) (void)hipFree(net->sk_cnt);
-        net->sk_ws = nullptr;
-        net->sk_cnt = nullptr;
-        return fail(Y3_ERR_OOM, "stream-K workspace: %s", hipGetErrorString(e));
-    }
-    return Y3_OK;
-}
-
 y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
 {
     if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::TILE_COUNT)
@@ -625,14 +600,9 @@ y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
         if (!y3::conv_tile_built(tile))
-            return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile %d is not in this build (experimental tiles: csrc/build.py --experimental)", tile);
-        if (is_probe_tile_f32(tile) && !probes_allowed())
-            return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile %d is a timing-only probe (set Y3_ALLOW_PROBE_TILES=1 to use it)", tile);
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile id %d is retired (the timing ablations of rounds 1-2; y3_tile_built)", tile);
         y3::TileInfo s = y3::conv_tile_info(tile);
         if (c.first_layer || c.cout_pad % s.bn) return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile does not divide Cout");
-        // a stream-K tile on an already planned fp32 net: its workspace is allocated on first use, not for everybody
-        if (s.sk && net->image_size && net->dtype == Y3_DTYPE_F32)
-            if (y3_status st = ensure_sk_workspace(net); st != Y3_OK) return st;
     }
     c.tile = tile;
     return Y3_OK;
@@ -645,7 +615,7 @@ y3_status y3_net_set_tile_bf16(y3_net *net, int slot, int tile)
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
         if (!y3::conv_bf16_tile_built(tile))
-            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile %d is not in this build (csrc/build.py --experimental)", tile);
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile id %d is retired (the pipelined tile of round 2; y3_tile_built)", tile);
         y3::TileInfo s = y3::conv_bf16_tile_info(tile);
         if (c.first_layer || c.cout_pad % s.bn || c.d.cin % s.stages || (c.d.src1 >= 0 && c.d.c0 % s.stages))
             return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile does not fit this conv");
@@ -674,8 +644,6 @@ y3_status y3_net_set_tile_x2(y3_net *net, int slot, int tile)
         return fail(Y3_ERR_INVALID, "y3_net_set_tile_x2: bad argument");
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
-        if (is_probe_tile_x2(tile) && !probes_allowed())
-            return fail(Y3_ERR_INVALID, "y3_net_set_tile_x2: tile %d is a timing-only probe (set Y3_ALLOW_PROBE_TILES=1 to use it)", tile);
         y3::TileInfo s = y3::conv_x3_tile_info(tile);
         if (!y3::conv_x2_tile_built(tile) || c.first_layer || c.cout_pad64 % s.bn || c.d.cin % s.stages ||
             (c.d.src1 >= 0 && c.d.c0 % s.stages))
@@ -716,13 +684,6 @@ y3_status y3_net_set_xcd_mode(y3_net *net, int mode)
 {
     if (!net || mode < 0 || mode > 1) return fail(Y3_ERR_INVALID, "y3_net_set_xcd_mode: mode must be 0 or 1");
     net->xcd_mode = mode;
-    return Y3_OK;
-}
-
-y3_status y3_net_set_sk_grid(y3_net *net, int workgroups)
-{
-    if (!net || workgroups < 0) return fail(Y3_ERR_INVALID, "y3_net_set_sk_grid: bad argument");
-    net->sk_grid = workgroups;
     return Y3_OK;
 }
 
@@ -768,7 +729,7 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
             if (net->convs[i].loaded && !net->convs[i].x2_ok)
                 return fail(Y3_ERR_INVALID, "y3_net_plan: conv %zu has a BN-scaled weight outside the fp16 range (|w| >= 65504); "
                                             "the two-plane mode cannot represent it, use Y3_DTYPE_F32 or Y3_DTYPE_F32X3", i);
-    HIP_TRY(hipSetDevice(net->device));
+    Y3_ENTER_DEVICE(net);
     free_plan(net);
     net->max_batch = max_batch;
     net->image_size = image_size;
@@ -859,18 +820,6 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
         net->tblock[t] = pool[pick].bytes;
     }
     if (y3_status st = ensure_lanes(net); st != Y3_OK) return st;
-    if (dtype == Y3_DTYPE_F32) {
-        // stream-K tiles (experimental builds) sum cut tiles through a workspace: allocated only when a conv slot asks
-        // for such a tile -- here if one is already set, in y3_net_set_tile otherwise
-        bool any_sk = false;
-        for (const ConvSlot &c : net->convs)
-            if (c.tile >= 0 && y3::conv_tile_info(c.tile).sk) any_sk = true;
-        if (any_sk)
-            if (y3_status st = ensure_sk_workspace(net); st != Y3_OK) {
-                free_plan(net);
-                return st;
-            }
-    }
     {   // Y3_STEM_MODE (tools: same-process-tree A/B of the stem forms) overrides the default, not an explicit setter call
         static const int env = [] { const char *e = getenv("Y3_STEM_MODE"); return e ? atoi(e) : -1; }();
         if (env >= 0 && env <= 2 && !net->stem_mode_set) net->stem_mode = env;
@@ -1000,11 +949,6 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.src1_bytes = d.src1 >= 0 ? (unsigned)bytes(d.src1) : 0;
             a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * sizeof(float));
             a.dst_bytes = (unsigned)bytes(d.dst);
-            a.sk_ws = net->sk_ws ? static_cast<char *>(net->sk_ws) + (size_t)lane * net->sk_ws_lane_bytes : nullptr;
-            a.sk_cnt = net->sk_cnt ? net->sk_cnt + (size_t)lane * net->sk_cnt_cap : nullptr;
-            a.sk_ws_bytes = (unsigned)net->sk_ws_lane_bytes;
-            a.sk_cnt_cap = net->sk_cnt_cap;
-            a.sk_grid_override = net->sk_grid;
             a.xcd_gn = 0;
             a.k_chunk = 0;
             a.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : (net->clk_conv == -2 && net->clk_stamps) ? net->clk_stamps + 8 * o.index : nullptr;   // fp32 MFMA kernel and stem only
@@ -1069,7 +1013,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * 2);
                 const bool out_f32 = is_out(d.dst);
                 if (d.residual >= 0 && out_f32) return fail(Y3_ERR_INVALID, "conv %d: residual on a head output is not supported in bf16 mode", o.index);
-                const int tile = c.tile_bf16 >= 0 ? c.tile_bf16 : choose_tile_bf16(c, a.M);
+                const int tile = c.tile_bf16 >= 0 ? c.tile_bf16 : choose_tile_bf16(c, a.M, (long long)net->max_batch * a.Ho * a.Wo);
                 e = y3::launch_conv_bf16(a, tile, out_f32, s);
             } else if (c.first_layer) {
                 e = y3::launch_conv_first_f32(a, c.w_dev, s);
@@ -1144,13 +1088,10 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
     for (int i = 0; i < 3; ++i)
         if (!grids[i] || ((uintptr_t)grids[i] & 15)) return fail(Y3_ERR_INVALID, "y3_net_forward: grid %d null or not 16-byte aligned", i);
     if ((uintptr_t)images & 3) return fail(Y3_ERR_INVALID, "y3_net_forward: images not 4-byte aligned");
-    HIP_TRY(hipSetDevice(net->device));   // launches go to the net's device whatever the caller's current one is
+    Y3_ENTER_DEVICE(net);   // launches go to the net's device whatever the caller's current one is; restored on return
     // Images are independent, so the batch can run as `lanes` sub-batches on forked streams: while one sub-batch's
     // conv kernel drains (its last workgroups leave CUs under-occupied), the other sub-batch's kernel fills them.
     net->cur_batch = batch;
-    // stream-K ticket counters: zeroed (synchronously) by y3_net_plan and returned to zero by the last contributor of
-    // every cut tile, so consecutive launches and forwards share the array without a per-forward memset (measured: a
-    // memset node in front of the kernels of a captured forward is not reliably ordered before them on replay)
     int lanes = (ms_out || net->lanes < 2) ? 1 : net->lanes;
     while (lanes > 1 && batch / lanes < 1) --lanes;
     // leading segment in chunks small enough for their activations to stay in the 256 MB Infinity Cache between the
@@ -1167,7 +1108,6 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
         return run_slice(net, images, grids, b0, nb, st, ms_out, n_ms, lane, nl, k_early, -1);
     };
     if (lanes == 1) return run_lane(0, batch, s, 0, 1);
-    HIP_TRY(hipSetDevice(net->device));
     if (y3_status st = ensure_lanes(net); st != Y3_OK) return st;
     HIP_TRY(hipEventRecord(net->fork_ev, s));
     // equal sub-batches (measured with tools/lanes_sweep.py: weighted 2:3 / 3:4:5 splits were 2-3 % slower)
@@ -1274,7 +1214,7 @@ namespace {
 y3_status measure_sclk_arrays(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
                               int pick, float *mhz_out, double *start_us, double *end_us, void *stream)
 {
-    HIP_TRY(hipSetDevice(net->device));
+    Y3_ENTER_DEVICE(net);
     const size_t nconv = net->convs.size();
     const size_t words = pick == -2 ? 8 * nconv : 8;   // per conv: memtime, realtime at entry; the same after the epilogue; realtime at the entry of workgroup 0
     std::vector<unsigned long long> host(words, 0ull);
@@ -1479,7 +1419,7 @@ y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const f
     if (batch > net->max_batch) return fail(Y3_ERR_INVALID, "y3_net_detect: batch %d > planned %d", batch, net->max_batch);
     if (max_boxes <= 0 || max_boxes > Y3_MAX_OUTPUT_BOXES)
         return fail(Y3_ERR_INVALID, "y3_net_detect: max_boxes must be in [1,%d]", Y3_MAX_OUTPUT_BOXES);
-    HIP_TRY(hipSetDevice(net->device));   // the decode / NMS / pack launches below go to the net's device, whatever the caller's current one
+    Y3_ENTER_DEVICE(net);   // the decode / NMS / pack launches below go to the net's device; the caller's current device is restored on return
     int32_t gs[3];
     size_t gelems[3], n = 0, off[9];
     detect_layout(net, batch, off, &n, gs, gelems);

@@ -26,14 +26,7 @@ struct ConvArgs {
     int M;                 // B*Ho*Wo
     int K;                 // ksize*ksize*Cin
     unsigned src0_bytes, src1_bytes, w_bytes, dst_bytes;
-    // stream-K schedule (fp32 tiles with TileInfo.sk): partial-tile slabs and per-tile ticket counters, owned by the net
-    void *sk_ws;           // >= 2 * workgroups * BM * BN * 4 bytes
-    int *sk_cnt;           // [sk_cnt_cap] zero between launches (the last contributor of a tile resets its counter)
-    unsigned sk_ws_bytes;
-    int sk_cnt_cap;
-    int sk_tiles;          // filled by the launcher: tilesM * tilesN
-    int sk_grid_override;  // > 0: number of workgroups instead of "everything resident at once" (tests)
-    // fp32 classic schedule: 0 = every XCD takes a contiguous run of tiles (N fastest); gn in {1,2,4,8} = the XCDs form
+    // fp32 tile order: 0 = every XCD takes a contiguous run of tiles (N fastest); gn in {1,2,4,8} = the XCDs form
     // an (8/gn) x gn grid over the (M-tile, N-tile) matrix (see conv_f32.hip)
     int xcd_gn;
     int k_chunk;           // fp32 MFMA kernel, 3x3 convs: > 0 walks K chunk-major, k_chunk input channels at a time (conv_f32.hip); 0: tap-major
@@ -57,10 +50,10 @@ inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes)
 }
 
 // tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
-static constexpr int TILE_COUNT = 46;  // 20..22, 25: timing-only probes; 33..40: stream-K schedule; 41..45: residual prefetch
-struct TileInfo { int bm, bn, waves, stages; int sk = 0; };
+static constexpr int TILE_COUNT = 33;  // 20..22, 25: retired ids (the timing-only probes of rounds 1-2)
+struct TileInfo { int bm, bn, waves, stages; };
 TileInfo conv_tile_info(int tile);
-bool conv_tile_built(int tile);        // false: experimental tile left out of this build
+bool conv_tile_built(int tile);        // false: retired id
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
 // first layer: 3x3 stride-1 conv with Cin=3 (direct, VALU)
@@ -94,7 +87,7 @@ struct StemArgs {
     unsigned long long *clk_stamps;  // [4]
 };
 hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s);
-hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s);   // conv0 in fp32 arithmetic, bf16 patch, conv1 on bf16 MFMA
+hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s);   // conv0 on bf16 MFMA from split (hi + lo) operands (~2^-16 per product), bf16 patch, conv1 on bf16 MFMA
 
 // bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
 static constexpr int BF16_TILE_COUNT = 32;
@@ -105,7 +98,7 @@ hipError_t launch_conv_first_bf16(const ConvArgs &a, const float *w_hwio_dev, hi
 hipError_t launch_bf16_to_f32(const void *x, float *y, size_t n, hipStream_t s);
 
 // fp32-accurate path on the bf16 matrix cores, three bf16 planes per value (conv_f32x3.hip); TileInfo.stages holds BK
-static constexpr int X3_TILE_COUNT = 46;
+static constexpr int X3_TILE_COUNT = 34;
 TileInfo conv_x3_tile_info(int tile);
 hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);
 hipError_t launch_conv_first_f32x3(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);

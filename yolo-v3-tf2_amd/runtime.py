@@ -35,6 +35,24 @@ def _need_cuda(*ts):
             raise Y3Error("expected contiguous CUDA(HIP) tensors; the y3 kernels have no CPU fallback")
 
 
+def tuning_table_path(tag: str, batch: int, image_size: int) -> str:
+    """The tile table of a plan: tuning/<mode>_b<batch>_s<size>.json of the package (may not exist: heuristic tiles).
+    Y3_TUNING_FILE (tools: A/B of tables) replaces it only for the plan it was made for: the file names its mode
+    ("dtype": "f32" | "bf16" | "f32x3" | "f32x2") and its batch / image_size; a plan of another mode or geometry in the
+    same process (bench.py's alt measurements re-plan the net) keeps its own packaged table."""
+    import json
+    import os
+    from . import PACKAGE_DIR
+    path = os.path.join(PACKAGE_DIR, "tuning", f"{tag}_b{batch}_s{image_size}.json")
+    override = os.environ.get("Y3_TUNING_FILE")
+    if override and os.path.exists(override):
+        with open(override) as f:
+            odoc = json.load(f)
+        if odoc.get("dtype") == tag and int(odoc.get("batch", -1)) == batch and int(odoc.get("image_size", -1)) == image_size:
+            path = override
+    return path
+
+
 class Net:
     """Device-side network = the fused conv program (reference counterpart: the Keras Model returned by
     ParseModel.build_model, core/parse_model.py:279-314)."""
@@ -115,10 +133,6 @@ class Net:
         the Darknet-53 stem and the plan is fp32 or bf16 without keep_activations).  2: conv0 + conv1 only."""
         check(self.lib.y3_net_set_stem_fusion(self._h, int(on)), "y3_net_set_stem_fusion")
 
-    def set_sk_grid(self, workgroups: int):
-        """Number of persistent workgroups of the stream-K conv tiles (0 = everything resident at once)."""
-        check(self.lib.y3_net_set_sk_grid(self._h, int(workgroups)), "y3_net_set_sk_grid")
-
     def set_early_chunk(self, n_convs: int, chunk_images: int):
         """Before plan(): the first n_convs convs run chunk_images images at a time (their activations then stay in the
         Infinity Cache between producer and consumer); 0, 0 switches it off."""
@@ -166,10 +180,8 @@ class Net:
         otherwise the library's heuristic stays in force."""
         import json
         import os
-        from . import PACKAGE_DIR
         tag = _lib.DTYPE_TAGS[self.dtype]
-        name = f"{tag}_b{self.max_batch}_s{self.image_size}.json"
-        path = os.environ.get("Y3_TUNING_FILE") or os.path.join(PACKAGE_DIR, "tuning", name)   # the override: A/B of tables (tools)
+        path = tuning_table_path(tag, self.max_batch, self.image_size)
         kind, fn = {_lib.Y3_DTYPE_F32: ("", self.lib.y3_net_set_tile), _lib.Y3_DTYPE_BF16: ("_bf16", self.lib.y3_net_set_tile_bf16),
                     _lib.Y3_DTYPE_F32X3: ("_x3", self.lib.y3_net_set_tile_x3),
                     _lib.Y3_DTYPE_F32X2: ("_x2", self.lib.y3_net_set_tile_x2)}[self.dtype]
