@@ -1,11 +1,7 @@
 #!/bin/bash
-# visit 4e: kernel-trace timeline of the bf16 step (2 lanes, graph replay): attributed time per kernel and grid
+# visit 4e: three prologues of the classic fp32 kernel on one box: arithmetic (r03), arithmetic + lean 1x1 (compile-time), row tables + lean 1x1
 set -o pipefail
-export TMPDIR=/tmp
-out=gpurun_out/trace_bf16
-mkdir -p $out
-timeout -k 10 300 rocprofv3 --kernel-trace -d $out -o run --output-format csv -- python3 bench.py --dtype bf16 --batch 128 --graph --steps 8 --warmup 3 --no-cpu-baseline > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
-f=$(find $out -name "*kernel_trace.csv" | head -1)
-python3 tools/timeline_share.py $f 4 > gpurun_out/4e_timeline_bf16.txt 2>&1 || { tail gpurun_out/4e_timeline_bf16.txt; exit 1; }
-head -40 gpurun_out/4e_timeline_bf16.txt
-rm -rf $out
+mkdir -p gpurun_out
+L=yolo-v3-tf2_amd/lib
+timeout -k 10 900 python tools/ab_libs.py $L/liby3hip_arith.so $L/liby3hip_arith_lean.so $L/liby3hip.so --rounds 4 > gpurun_out/r4e_ab_prologues.txt 2>&1 || { tail -20 gpurun_out/r4e_ab_prologues.txt; exit 1; }
+grep -v amdgpu gpurun_out/r4e_ab_prologues.txt | tail -16
