@@ -121,13 +121,15 @@ def test_conv_every_tile_shape(rt, tile):
 
 
 @pytest.mark.parametrize("tile", [33, 34, 35, 36, 37])
-@pytest.mark.parametrize("slots", [0, 1])
-def test_persistent_tiles_bit_identical_to_classic(rt, tile, slots):
+@pytest.mark.parametrize("slots,S,B", [(0, 40, 5), (1, 40, 5), (1, 160, 6)])
+def test_persistent_tiles_bit_identical_to_classic(rt, tile, slots, S, B):
     """Persistent form of the fp32 conv kernel (csrc/conv_f32p.hip): workgroups walking several tiles, the operand ring running
     across tile boundaries, row state from the plan-time tables.  Every conv flavour -- 3x3 stride 1 and 2, with a shortcut,
     1x1, the bias head with Cout = 255 (ragged N), ragged M; up-sample + concat in the whole-network test below -- must give the SAME BITS as the classic tile of
-    the same block shape (same per-output K order), with the occupancy query's grid and with one workgroup per CU (slots = 1:
-    3 x 40^2 gives 75..300 tiles for 256 workgroups on some convs -> multi-tile walks, and fewer tiles than workgroups on others)."""
+    the same block shape (same per-output K order), with the occupancy query's grid and with one workgroup per CU (slots = 1).
+    5 x 40^2: a few dozen to a few hundred tiles -> all-static launches, some with fewer tiles than workgroups; 6 x 160^2 with 256
+    workgroups: 600..1200 tiles -> whole owned rounds + left-over positions PULLED through the per-XCD cursors, several launches in
+    a row on the same cursors (the last workgroup of each launch zeroes them)."""
     from tests.helpers import mini_program
     from yolo_v3_tf2_amd.weights import synthetic_weights
     from yolo_v3_tf2_amd import _lib
@@ -137,7 +139,6 @@ def test_persistent_tiles_bit_identical_to_classic(rt, tile, slots):
     heads = [dict(filters=bn, size=3), dict(filters=255, size=1, bn=False, act="linear"), dict(filters=bn, size=3, stride=2)]
     p = mini_program(64, chain, heads)
     w = synthetic_weights(p, seed=33)
-    B, S = 5, 40
     x = np.random.default_rng(33).standard_normal((B, S, S, 64)).astype(np.float32)
     ref = O.forward(p, w, x)
     outs = {}
@@ -166,11 +167,12 @@ def test_persistent_tiles_whole_network_bit_identical(rt, program, weights, anch
     from yolo_v3_tf2_amd import _lib
     x = _cuda(np.random.default_rng(34).random((B, S, S, 3), dtype=np.float32))
     outs = {}
-    for name, pick in (("classic", lambda o: 26 if o.cout % 128 == 0 else 27), ("persistent", lambda o: 33 if o.cout % 128 == 0 else 34)):
+    pad = lambda o: (o.cout + 31) // 32 * 32      # noqa: E731  (Cout = 255 heads run with 256 padded channels)
+    for name, pick in (("classic", lambda o: 26 if pad(o) % 128 == 0 else 27), ("persistent", lambda o: 33 if pad(o) % 128 == 0 else 34)):
         net = rt.Net(program)
         net.load_weights(weights)
         for slot, o in enumerate(net.conv_ops):
-            if o.cin != 3:
+            if o.cin != 3 and pad(o) % 64 == 0:       # (the 64 -> 32 conv of the stem keeps the heuristic tile in both plans)
                 net.set_tile(slot, pick(o))
         net.plan(B, S)
         for lanes in (1, 2):
@@ -1703,9 +1705,9 @@ def test_fused_stem_bf16_conv0_error_bounded_through_identity_heads(rt, S, B):
         beyond = float((d > ulp + 1e-5 * scale).mean())     # more than the element's own rounding: a flipped conv0 value upstream
         print(f"stem conv1 output, {name}: {100 * frac:.2f} % of elements differ, {100 * beyond:.3f} % by more than their own ulp, "
               f"max |d| = {d.max() / (2.0 ** -8 * scale):.3f} ulp of the layer's scale")
-        # a conv0 value rounded the other way (1 bf16 ulp of ITS magnitude) moves a conv1 sum by |w| * ulp: bounded by one ulp of
-        # the layer's scale in absolute terms, however small the element itself is (sums cancel)
-        assert d.max() <= _bf16_ulp(ref), (name, float(d.max()))
+        # a conv0 value rounded the other way (1 bf16 ulp of ITS magnitude) moves a conv1 sum by |w| * ulp -- an absolute amount
+        # however small the element itself is (sums cancel): the element's own rounding + 2^-8 of the layer's scale bounds it
+        assert (d <= ulp + 2.0 ** -8 * scale).all(), (name, float(d.max()))
         assert frac <= 0.05 and beyond <= 0.01, (name, frac, beyond)
 
 

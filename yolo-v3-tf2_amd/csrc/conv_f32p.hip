@@ -3,8 +3,16 @@
 // Same fused op and the same arithmetic as conv_f32.hip (reference: core/parse_model.py:27-52,72,134,155-156): every output is
 // the same k-ordered sum, so results are BIT-IDENTICAL to the classic tiles (tests/test_gpu_parity.py::test_conv_every_tile_shape
 // and test_persistent_tiles_bit_identical_to_classic).  What changes is who pays for what outside the K loop:
-//   * a launch has as many workgroups as the chip holds at once (occupancy x CUs); workgroup w walks the tiles w, w + G, w + 2G ...
-//     of the classic tile order (so the workgroups running at any moment still share activation rows / weight rows in one L2);
+//   * a launch has as many workgroups as the chip holds at once (occupancy x CUs).  Workgroup w OWNS positions w, w + G, ... of
+//     the classic tile order for the whole rounds of the launch (the workgroups running at any moment still share activation
+//     rows / weight rows in one L2); the fewer-than-G positions left over are PULLED by whoever gets there first, from one cursor
+//     per XCD (a workgroup whose XCD has run dry takes from the others), so that a launch of 7.04 rounds is not paid as 8
+//     (profiles/r04_tile_sweep_f32_persistent_static_b64_s416.txt: the all-static first build, -4 % against the classic tiles on the
+//     large layers; pulling EVERY tile, the second build, cost more than it balanced: r04_tile_sweep_f32_persistent_pull_all_*.txt,
+//     1x1 layers 110 -> 65 TFLOP/s -- the returning atomic sits in the wave's memory queue in front of the next K tile).  A pull
+//     is one relaxed agent-scope atomic add by one lane, issued a tile ahead of its use and handed to the other waves through an
+//     LDS word behind a barrier the K loop has anyway; nobody waits for anybody (no spin).  The last workgroup to leave zeroes the
+//     cursors for the next launch (cdna_hip_programming.md Guideline 16: counters, not flags);
 //   * the operand ring (two LDS stages, direct-to-LDS buffer loads) runs ACROSS tile boundaries: the first K tile of the next
 //     output tile is requested at the top of the current tile's last K iteration, so it lands under that iteration's MFMAs and
 //     the epilogue; no wave ever sits in "first fetch + barrier";
@@ -50,8 +58,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_pers(const ConvAr
     const int wr = wave / WC, wc = wave % WC;
     const int fr = lane & 31, fh = lane >> 5;
 
-    // ---- the tile sequence of this workgroup: positions bid, bid + G, ... of the classic launch order ---------------------
-    const int G = (int)gridDim.x;            // a multiple of 8: all tiles of a workgroup belong to its XCD's share
+    // ---- positions 0 .. T-1 of the classic launch order: position l belongs to XCD l & 7 ---------------------------------
     const int tilesN = p.CoutPad / BN;
     const int tilesM = (p.M + BM - 1) / BM;
     const int KT = p.K / PBK;
@@ -86,14 +93,58 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_pers(const ConvAr
         n0 = nt * BN;
         return true;
     };
-    auto next_pos = [&](int l, int &m0, int &n0) -> int {   // first valid position >= l on this workgroup's walk, or T
-        while (l < T && !coords(l, m0, n0)) l += G;
-        return l < T ? l : T;
+    // ---- who runs which position ------------------------------------------------------------------------------------------
+    // Workgroup w OWNS positions w, w + G, ... of the first RS whole rounds (G = gridDim.x, a multiple of 8: all of them in one
+    // XCD's share); the T - RS * G positions left over (fewer than G) are PULLED by whoever gets there: one cursor per XCD counts
+    // the left-over positions of that XCD's share that have been handed out, a workgroup whose XCD has run dry takes from the
+    // others.  A launch of fewer than two whole rounds (and every launch when p.pers_ctr is null) is all static.
+    int *const ctr = p.pers_ctr;                                                   // [0..7] one cursor per XCD, [8] workgroups that have left
+    const int G = (int)gridDim.x;
+    const bool dynamic = ctr != nullptr && T >= 2 * G && T % G != 0;
+    const int RS = dynamic ? T / G : (T + G - 1) / G;                              // static rounds
+    const int S_lim = dynamic ? RS * G : T;                                        // positions below S_lim are owned, the others pulled
+    const int jbase = (RS * G) >> 3;                                               // left-over position c of XCD x: x + 8 * (jbase + c)
+    const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7);         // HW_REG_XCC_ID: which cursor to pull from first (speed only)
+    auto lshare = [&](int x) { return (gn > 0 ? rows_x * nb_x : (T >> 3) + (x < (T & 7) ? 1 : 0)) - jbase; };   // left-over positions of XCD x
+    // wave 0 only, dynamic launches only.  A left-over position for this workgroup, or T when they have all been handed out.
+    // One 32-byte look at the eight cursors tells which XCDs still have any; the atomic add that follows can still lose a race.
+    auto pull_sync = [&]() -> int {
+        for (;;) {
+            int c = 0x7fffffff;
+            if (lane < 8) c = __hip_atomic_load(ctr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned avail = (unsigned)__builtin_amdgcn_ballot_w64(lane < 8 && c < lshare(lane)) & 0xffu;
+            if (!avail) return T;
+            const unsigned rot = ((avail >> xcd) | (avail << (8 - xcd))) & 0xffu;   // bit k: XCD (xcd + k) & 7
+            const int x = (xcd + __builtin_ctz(rot)) & 7;
+            int j = 0;
+            if (lane == 0) j = __hip_atomic_fetch_add(ctr + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            j = __builtin_amdgcn_readfirstlane(j);
+            int mm, nn;
+            if (j < lshare(x) && coords(x + 8 * (jbase + j), mm, nn)) return x + 8 * (jbase + j);   // (padding positions of a blocked split are skipped)
+        }
     };
-
+    auto leave = [&]() {   // dynamic launches: every workgroup, once, after its last pull; the last one to leave zeroes the cursors for the next launch
+        if (dynamic && tid == 0) {
+            const int old = __hip_atomic_fetch_add(ctr + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == G - 1) {
+                for (int x = 0; x < 9; ++x) __hip_atomic_store(ctr + x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    auto next_owned = [&](int l) -> int {   // first valid owned position >= l on this workgroup's walk, or T
+        int mm, nn;
+        while (l < S_lim && !coords(l, mm, nn)) l += G;
+        return l < S_lim ? l : T;
+    };
+    int *const slot = reinterpret_cast<int *>(smem + 2 * STAGE);   // two words behind the ring: pulled positions handed from wave 0 to the others
+    int pos = next_owned((int)blockIdx.x);
+    if (pos >= T) {   // (more workgroups than tiles, or only padding positions: possible in all-static launches only)
+        leave();
+        return;
+    }
+    int posn = next_owned(pos + G);   // dynamic launches have RS >= 2: the second tile is owned as well (blocked splits may lack it; they then stop early)
     int m0 = 0, n0 = 0;
-    int pos = next_pos((int)blockIdx.x, m0, n0);
-    if (pos >= T) return;
+    coords(pos, m0, n0);
 
     // ---- per-workgroup constants -------------------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.src0), 0, p.src0_bytes, 0x00020000);
@@ -172,7 +223,9 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_pers(const ConvAr
         tap = 0;
         c0 = 0;
         cend = CK;
-        nK4 = n0_ * p.K * 4;
+        // (readfirstlane: the tile position has been through an LDS word and loop-carried selects; hipcc must be able to PROVE the
+        // scalar offset of the buffer loads wave-uniform or it wraps every one of them in a waterfall loop -- cdna_hip_programming.md T20)
+        nK4 = __builtin_amdgcn_readfirstlane(n0_ * p.K * 4);
         set_tap();
     };
 
@@ -205,6 +258,18 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_pers(const ConvAr
         kglob = tap * p.Cin + c0;
     };
 
+    // ---- start stagger ----------------------------------------------------------------------------------------------------
+    // The R workgroups of a CU start together and run equal work: left alone they reach their epilogues (and their first-K-tile
+    // waits) together, launch after launch, and the matrix pipe idles through all of them at once -- the classic launch does not
+    // have this problem (its workgroups are dispatched whenever a slot frees up).  Group r of R (workgroups r * G / R ...: the
+    // dispatcher deals the first G / R workgroups one to a CU, then the next G / R) sleeps r x pers_stagger % of the matrix time of
+    // one tile before its first fetch, so that the CU's workgroups run out of phase.  Speed only.
+    if (p.pers_stagger > 0 && p.pers_groups > 1 && G % p.pers_groups == 0) {
+        const int grp = (int)blockIdx.x / (G / p.pers_groups);
+        const long long cyc = (long long)grp * KT * 32 * TM * TN * 64 * p.pers_stagger / 100;
+        for (long long c = 0; c < cyc; c += 127 * 64) __builtin_amdgcn_s_sleep(127);
+    }
+
     // ---- first tile of this workgroup -------------------------------------------------------------------------------------
     request_rows(m0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -215,11 +280,27 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_pers(const ConvAr
     __syncthreads();
 
     const int row_bytes = p.Cout * 4;
-    for (;;) {
+    for (int it = 0;; ++it) {
         int m0n = 0, n0n = 0;
-        const int posn = next_pos(pos + G, m0n, n0n);
         const bool has_next = posn < T;
-        if (has_next) request_rows(m0n);   // lands under the K loop (every iteration ends in s_waitcnt vmcnt(0))
+        // the position AFTER the next one: owned (arithmetic), or -- past this workgroup's owned rounds -- pulled: the atomic is
+        // issued here by one lane, resolved by wave 0 in the last K iteration and read by everybody after the epilogue
+        int posnn = T, pend = 0;
+        bool pulled = false;
+        if (has_next) {
+            coords(posn, m0n, n0n);
+            m0n = __builtin_amdgcn_readfirstlane(m0n);
+            n0n = __builtin_amdgcn_readfirstlane(n0n);
+            if (posn < S_lim) posnn = next_owned(posn + G);
+            pulled = dynamic && posnn >= T;
+            // The table entries of the next tile (and the pull) are requested at the END of the first K iteration, behind that
+            // iteration's operand fetch: vector-memory operations complete in issue order, so requested at the top they would sit in
+            // front of the K tile the iteration waits for -- a cold read (and a returning atomic) in front of an L2 hit, once per tile.
+            if (KT == 1) {
+                request_rows(m0n);
+                if (pulled && wave == 0 && lane == 0) pend = __hip_atomic_fetch_add(ctr + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
 
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -237,26 +318,50 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_pers(const ConvAr
                 if (KT == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the table entries were requested in this very iteration)
                 apply_rows(m0n, n0n);
                 fetch(stage ^ 1);
+                if (pulled && wave == 0) {   // the pull issued at the top of this tile has returned: resolve it and hand it over
+                    const int j = __builtin_amdgcn_readfirstlane(pend);
+                    int mm, nn, q = xcd + 8 * (jbase + j);
+                    if (j >= lshare(xcd) || !coords(q, mm, nn)) q = pull_sync();
+                    if (lane == 0) slot[it & 1] = q;   // read by every wave after this iteration's barrier; rewritten two tiles on at the earliest
+                }
             }
-            const float *sa = smem + stage * STAGE + a_frag;
-            const float *sb = smem + stage * STAGE + b_frag;
+            // (two copies of the block, one per ring stage: with the stage in a register every fragment address costs a vector add)
+            auto mma = [&](auto stage_tag) {
+                constexpr int ST = decltype(stage_tag)::value;
+                const float *sa = smem + ST * STAGE + a_frag;
+                const float *sb = smem + ST * STAGE + b_frag;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 fa[TM], fb[TN];
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(sa + i * 32 * PBK + foff[q]);
+                    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(sa + i * 32 * PBK + foff[q]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(sb + j * 32 * PBK + foff[q]);
+                    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(sb + j * 32 * PBK + foff[q]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+                }
+            };
+            if (stage == 0) mma(std::integral_constant<int, 0>{}); else mma(std::integral_constant<int, 1>{});
+            // the K tile requested at the top has landed -- for every wave, after the barrier -- and every wave is done reading this
+            // stage (its fragment reads were consumed by its MFMAs).  Raw s_barrier + explicit counts: __syncthreads() would drain
+            // the memory queue, and the first iteration leaves the table entries / the pull of the next tile in flight.
+            constexpr int NTAB = MODE == 1 ? 0 : AP;
+            if (kt == 0 && has_next && KT > 1) {
+                request_rows(m0n);
+                if (pulled && wave == 0) {
+                    if (lane == 0) pend = __hip_atomic_fetch_add(ctr + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NTAB + 1) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NTAB) : "memory");
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K tile requested at the top has landed
-            __syncthreads();                                   // ... for every wave, and every wave is done reading this stage
             stage ^= 1;
         }
 
@@ -327,9 +432,11 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_pers(const ConvAr
 
         if (!has_next) break;
         pos = posn;
+        posn = __builtin_amdgcn_readfirstlane(pulled ? slot[it & 1] : posnn);
         m0 = m0n;
         n0 = n0n;
     }
+    leave();
 }
 
 // resident workgroups per CU of an instantiation on a device (occupancy query once per (instantiation, device))
@@ -339,7 +446,7 @@ template <int TM, int TN, int WR, int WC, int MODE, int MINW>
 hipError_t launch_pers(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC, NT = 64 * WR * WC;
-    const size_t lds = 2 * (size_t)(BM + BN) * PBK * sizeof(float);
+    const size_t lds = 2 * (size_t)(BM + BN) * PBK * sizeof(float) + 16;   // the ring + the two hand-over words
     auto k = conv_f32_pers<TM, TN, WR, WC, MODE, MINW>;
     static LdsAttrOnce attr;
     if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
@@ -368,9 +475,12 @@ hipError_t launch_pers(const ConvArgs &a, hipStream_t s)
     if (a.pers_wg_per_cu > 0 && a.pers_wg_per_cu < per_cu) per_cu = a.pers_wg_per_cu;
     int grid = per_cu * res.cus[dev];
     grid -= grid % 8;
-    if (grid > T) grid = (T + 7) / 8 * 8;   // fewer tiles than slots: one tile each (positions >= T exit at once)
+    if (grid > T) grid = (T + 7) / 8 * 8;   // fewer tiles than slots: about one tile each
     if (MODE != 1 && (!a.rowtab || a.rowtab_bytes < (unsigned)a.M * 8u)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, s, a);
+    if (!a.pers_ctr) return hipErrorInvalidValue;
+    ConvArgs b = a;
+    b.pers_groups = (grid == per_cu * res.cus[dev]) ? per_cu : 1;   // a full grid: per_cu workgroups on every CU
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, s, b);
     return hipGetLastError();
 }
 

@@ -135,6 +135,7 @@ struct y3_net {
     struct RowTab { int H, W, stride, size, up0, concat; void *dev; size_t rows; };
     std::vector<RowTab> rowtabs;
     std::vector<int> conv_rowtab;  // per conv slot: index into rowtabs or -1
+    int *pers_ctr = nullptr;       // tile cursors of the persistent tiles: 16 ints per lane, zeroed at plan time, returned to zero by every launch
     int pers_wg_per_cu = 0;        // y3_net_set_persistent_slots: cap on resident workgroups per CU of the persistent tiles (0: occupancy query)
     int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 (+ the 1x1 after them) as one kernel when the graph allows it; 2 = conv0 + conv1 only
     bool stem_mode_set = false;    // y3_net_set_stem_fusion was called (the Y3_STEM_MODE tool override then stays out)
@@ -163,6 +164,8 @@ void free_plan(y3_net *n)
     if (n->det_buf) (void)hipFree(n->det_buf);
     n->det_buf = nullptr;
     n->det_bytes = 0;
+    if (n->pers_ctr) (void)hipFree(n->pers_ctr);
+    n->pers_ctr = nullptr;
     for (auto &t : n->rowtabs) (void)hipFree(t.dev);
     n->rowtabs.clear();
     n->conv_rowtab.clear();
@@ -743,6 +746,8 @@ static y3_status build_row_tables(y3_net *net)
 {
     net->conv_rowtab.assign(net->convs.size(), -1);
     if (net->dtype != Y3_DTYPE_F32) return Y3_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->pers_ctr), Y3_MAX_LANES * 16 * sizeof(int)));
+    HIP_TRY(hipMemset(net->pers_ctr, 0, Y3_MAX_LANES * 16 * sizeof(int)));
     for (size_t ci = 0; ci < net->convs.size(); ++ci) {
         const ConvSlot &c = net->convs[ci];
         const y3_conv_desc &d = c.d;
@@ -1032,6 +1037,11 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.rowtab = nullptr;
             a.rowtab_bytes = 0;
             a.pers_wg_per_cu = net->pers_wg_per_cu;
+            {
+                static const int env = [] { const char *e = getenv("Y3_PERS_STAGGER"); return e ? atoi(e) : 100; }();   // tools: A/B of the start stagger
+                a.pers_stagger = env;
+            }
+            a.pers_ctr = net->pers_ctr ? net->pers_ctr + 16 * lane : nullptr;
             if (o.index < (int)net->conv_rowtab.size() && net->conv_rowtab[o.index] >= 0) {
                 a.rowtab = net->rowtabs[net->conv_rowtab[o.index]].dev;
                 a.rowtab_bytes = (unsigned)((size_t)nb * (net->image_size / d.out_div) * (net->image_size / d.out_div) * 8);

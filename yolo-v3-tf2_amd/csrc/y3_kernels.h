@@ -34,6 +34,9 @@ struct ConvArgs {
     // single-source 1x1 convs.  rowtab_bytes = 8 * M of THIS launch (rows beyond it read as zeros through the bounds check).
     const void *rowtab;
     unsigned rowtab_bytes;
+    int *pers_ctr;         // [9] ints, zero between launches: 8 per-XCD tile cursors + the count of workgroups that have left (owned by the net, one set per lane)
+    int pers_stagger;      // start stagger of the workgroups sharing a CU, in % of one tile's matrix time per group (0: none)
+    int pers_groups;       // filled by the launcher: workgroups per CU of a full grid (1: no stagger)
     int pers_wg_per_cu;    // > 0: cap on resident workgroups per CU of a persistent launch (tools); 0 = what the occupancy query says
     int k_chunk;           // fp32 MFMA kernel, 3x3 convs: > 0 walks K chunk-major, k_chunk input channels at a time (conv_f32.hip); 0: tap-major
     // measurement only (y3_net_measure_sclk): when non-null, thread 0 of the middle workgroup stores {s_memtime, s_memrealtime}
