@@ -121,12 +121,6 @@ y3_status y3_net_set_tile_x2(y3_net *net, int conv_slot, int tile);   /* same ti
  * stream: the tail of one sub-batch's conv kernel overlaps the next kernel of another.  Results are unchanged
  * (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
 y3_status y3_net_set_lanes(y3_net *net, int lanes);
-/* fp32 tiles 33..37 are the PERSISTENT form of the conv kernel (csrc/conv_f32p.hip): a launch has as many workgroups as the
- * chip holds at once, each walking tiles w, w + G, ... of the classic order with its operand ring running across tile
- * boundaries and its per-tile row state read from tables y3_net_plan builds.  Same per-output arithmetic as the classic
- * tiles: results are bit-identical.  y3_net_set_persistent_slots caps the resident workgroups per CU of such launches
- * (0 = what the occupancy query says); for tests and tuning. */
-y3_status y3_net_set_persistent_slots(y3_net *net, int workgroups_per_cu);
 /* Placement of the fp32 conv tiles on the 8 XCDs (each has a private 4 MB L2).  1 (default): per conv, the XCDs form an
  * (8/gn) x gn grid over the (pixel-tile, channel-tile) matrix, gn chosen so that an XCD's slice of the weights stays in
  * its L2 (the 256->512 / 512->1024 3x3 weights are 4.7 / 18.9 MB); 0: every XCD takes a contiguous run of tiles.

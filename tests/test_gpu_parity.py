@@ -120,69 +120,6 @@ def test_conv_every_tile_shape(rt, tile):
         assert np.abs(g - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
 
 
-@pytest.mark.parametrize("tile", [33, 34, 35, 36, 37])
-@pytest.mark.parametrize("slots,S,B", [(0, 40, 5), (1, 40, 5), (1, 160, 6)])
-def test_persistent_tiles_bit_identical_to_classic(rt, tile, slots, S, B):
-    """Persistent form of the fp32 conv kernel (csrc/conv_f32p.hip): workgroups walking several tiles, the operand ring running
-    across tile boundaries, row state from the plan-time tables.  Every conv flavour -- 3x3 stride 1 and 2, with a shortcut,
-    1x1, the bias head with Cout = 255 (ragged N), ragged M; up-sample + concat in the whole-network test below -- must give the SAME BITS as the classic tile of
-    the same block shape (same per-output K order), with the occupancy query's grid and with one workgroup per CU (slots = 1).
-    5 x 40^2: a few dozen to a few hundred tiles -> all-static launches, some with fewer tiles than workgroups; 6 x 160^2 with 256
-    workgroups: 600..1200 tiles -> whole owned rounds + left-over positions PULLED through the per-XCD cursors, several launches in
-    a row on the same cursors (the last workgroup of each launch zeroes them)."""
-    from tests.helpers import mini_program
-    from yolo_v3_tf2_amd.weights import synthetic_weights
-    from yolo_v3_tf2_amd import _lib
-    from oracle import oracle as O
-    bn = _lib.TILES[tile][1]
-    chain = [dict(filters=128, size=3, stride=2), dict(filters=64, size=1), dict(filters=128, size=3, shortcut=-3)]
-    heads = [dict(filters=bn, size=3), dict(filters=255, size=1, bn=False, act="linear"), dict(filters=bn, size=3, stride=2)]
-    p = mini_program(64, chain, heads)
-    w = synthetic_weights(p, seed=33)
-    x = np.random.default_rng(33).standard_normal((B, S, S, 64)).astype(np.float32)
-    ref = O.forward(p, w, x)
-    outs = {}
-    for t in (_lib.PERSISTENT_BASE[tile], tile):
-        net = rt.Net(p)
-        net.load_weights(w)
-        for slot, o in enumerate(net.conv_ops):
-            if o.cout % _lib.TILES[t][1] == 0 or o.cout == 255 and _lib.TILES[t][1] <= 128:
-                net.set_tile(slot, t)
-        net.plan(B, S)
-        net.set_persistent_slots(slots)
-        outs[t] = [g.clone() for g in net.forward(_cuda(x))]
-        again = net.forward(_cuda(x))
-        torch.cuda.synchronize()
-        assert all(torch.equal(a, b) for a, b in zip(outs[t], again))
-    for a, b, r in zip(outs[_lib.PERSISTENT_BASE[tile]], outs[tile], ref):
-        assert torch.equal(a, b)
-        assert np.abs(b.cpu().numpy().reshape(r.shape) - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
-
-
-@pytest.mark.parametrize("S,B", [(96, 3), (416, 2)])
-def test_persistent_tiles_whole_network_bit_identical(rt, program, weights, anchors, S, B):
-    """The whole YOLOv3 graph with every MFMA conv forced onto a persistent tile (64x64, which divides every Cout; then 64x128
-    where it divides): head grids bit-identical to the plan with the classic tiles of the same shapes, lanes 1 and 2, chunk-major K
-    on the deep 3x3 convs included (416: Cin >= 256 -> 128-channel chunks), fused stem in front."""
-    from yolo_v3_tf2_amd import _lib
-    x = _cuda(np.random.default_rng(34).random((B, S, S, 3), dtype=np.float32))
-    outs = {}
-    pad = lambda o: (o.cout + 31) // 32 * 32      # noqa: E731  (Cout = 255 heads run with 256 padded channels)
-    for name, pick in (("classic", lambda o: 26 if pad(o) % 128 == 0 else 27), ("persistent", lambda o: 33 if pad(o) % 128 == 0 else 34)):
-        net = rt.Net(program)
-        net.load_weights(weights)
-        for slot, o in enumerate(net.conv_ops):
-            if o.cin != 3 and pad(o) % 64 == 0:       # (the 64 -> 32 conv of the stem keeps the heuristic tile in both plans)
-                net.set_tile(slot, pick(o))
-        net.plan(B, S)
-        for lanes in (1, 2):
-            net.set_lanes(lanes)
-            outs[(name, lanes)] = [g.clone() for g in net.forward(x)]
-    for lanes in (1, 2):
-        for a, b in zip(outs[("classic", 1)], outs[("persistent", lanes)]):
-            assert torch.equal(a, b)
-
-
 def test_xcd_blocked_tile_order_is_bit_identical(rt):
     """Placement of the fp32 conv tiles on the 8 XCDs (y3_net_set_xcd_mode): the weight-heavy 3x3 convs take the
     XCD-blocked order (512->1024: 18.9 MB of weights -> every XCD one eighth of the channel tiles; 256->512 with 64x128

@@ -29,11 +29,7 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
          (128, 128, 4, 1), (128, 128, 4, 1),                # 23/24: 128x128 within 3 / 4 waves per SIMD of registers
          (0, 0, 0, 0),                                      # 25: retired id
          (64, 128, 4, 2), (64, 64, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (256, 32, 4, 2),  # 26..30: LDS-DMA operand loads
-         (64, 128, 4, 1), (64, 64, 4, 1),                   # 31, 32: LDS-DMA, single LDS stage
-         # 33..37: persistent workgroups, operand ring across tile boundaries, table-driven row state (csrc/conv_f32p.hip)
-         (64, 128, 4, 2), (64, 64, 4, 2), (128, 64, 8, 2), (128, 128, 4, 2), (128, 128, 8, 2)]
-PERSISTENT_TILES = (33, 34, 35, 36, 37)
-PERSISTENT_BASE = {33: 26, 34: 27, 35: 19, 36: 28, 37: 13}   # a classic tile of the same block shape (bit-identical results)
+         (64, 128, 4, 1), (64, 64, 4, 1)]                   # 31, 32: LDS-DMA, single LDS stage
 RETIRED_TILES = tuple(i for i, t in enumerate(TILES) if t[0] == 0)   # ids y3_tile_built answers 0 for
 # three-plane (fp32-accurate on bf16 MFMA) kernel tiles: (BM, BN, waves, BK)
 TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), (256, 64, 4, 32),
@@ -57,7 +53,7 @@ TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4
               (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64),  # 24..26: tiles 17..19 on 16x16x32 MFMAs
               (128, 128, 4, 64), (128, 64, 4, 64), (64, 128, 4, 64),       # 27..29: tiles 8, 10, 12 on 16x16x32 MFMAs
               (128, 64, 4, 32), (64, 64, 4, 32)]                          # 30, 31: LDS-DMA, BK 32, 64 output channels
-TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 else "") + ("pers" if i >= 33 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
+TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
 
 
 class Y3Error(RuntimeError):
@@ -98,7 +94,6 @@ SYMBOLS = {
     "y3_net_set_early_chunk": (_i, [_vp, _i, _i]),
     "y3_net_keep_activations": (_i, [_vp, _i]),
     "y3_net_set_lanes": (_i, [_vp, _i]),
-    "y3_net_set_persistent_slots": (_i, [_vp, _i]),
     "y3_net_set_xcd_mode": (_i, [_vp, _i]),
     "y3_net_set_k_chunk": (_i, [_vp, _i]),
     "y3_net_set_stem_fusion": (_i, [_vp, _i]),

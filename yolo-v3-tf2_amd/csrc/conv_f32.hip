@@ -56,17 +56,9 @@ __device__ int y3_dbg32_sel_k = -1;
 #define Y3_STAMP32(k) do { } while (0)
 #endif
 
-// KS: kernel size (1 or 3) at compile time -- the 1x1 instantiations carry no tap logic at all.
-// Row state (round 4): the per-row pixel offsets and tap masks come from the table y3_net_plan builds (ConvArgs.rowtab: int2 per
-// output row; 3x3: {pixel index of tap (0,0), 9-bit tap mask}, concat: {pixel index in src0, in src1}); a single-source 1x1 conv
-// needs none (row m is pixel m).  Before, every workgroup decomposed its rows with ~260 dependent vector instructions that each
-// waited for an issue slot between 64-cycle MFMAs of the CU's other waves: 20 us from kernel entry to the first fetch
-// (profiles/r03_f32_phase_stamps.txt).  -DY3_AB_ARITH_PROLOGUE builds the old arithmetic for A/Bs (tools/ab_libs.py).
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int MINW = 1, int DMA = 0, int KS = 3>
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int MINW = 1, int DMA = 0>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvArgs p)
 {
-    static_assert(KS == 1 || KS == 3, "1x1 or 3x3");
-    static_assert(!CONCAT || KS == 1, "the two-source gather is a 1x1 conv");
     Y3_STAMP32(0);
 #ifdef Y3_PHASE_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 32768 && p.K == y3_dbg32_sel_k) {
@@ -143,12 +135,11 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     // first float of this lane's 16-B piece inside the 32-float K tile (DMA: the piece that lands in physical chunk
     // tid & 7 of the row is logical chunk (tid & 7) ^ ((row >> 1) & 7); rows of a pass differ by multiples of 32)
     const int lchunk = DMA ? (((tid & 7) ^ ((lrow >> 1) & 7)) * 4) : (tid & 7) * 4;
-    const int C1 = p.Cin - p.C0;
-#ifdef Y3_AB_ARITH_PROLOGUE
     int aoff[AP];                      // element offset of (b, hi0, wi0, 0) in src0 (may be negative)
     int aoff1[CONCAT ? AP : 1];        // CONCAT: element offset of (b, ho, wo, 0) in src1
     int ahw[AP];                       // hi0 << 16 | (wi0 & 0xffff); row >= M marked by hi0 = -32768
     const int HoWo = p.Ho * p.Wo;
+    const int C1 = p.Cin - p.C0;
     // (b, ho, wo) of row m: the tile's first row is decomposed with wave-uniform (scalar) divisions; the lane's
     // displacement (< BM + Wo) is folded in with an exact small float division -- vector integer division costs
     // ~40 VALU instructions each, and VALU time is lost MFMA time for every wave on the SIMD.
@@ -160,13 +151,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + i * RP + lrow;
-#ifdef Y3_AB_LEAN_1X1
-        if (!CONCAT && KS == 1) {   // A/B build: arithmetic for 3x3 / concat, row m = pixel m for the single-source 1x1 convs
-            aoff[i] = m * p.Cin;
-            ahw[i] = (m < p.M) ? 0 : (int)0x80000000;
-            continue;
-        }
-#endif
         const int x = wo0 + i * RP + lrow;                       // < BM + Wo <= 1024: (x+0.5)*rcp is exact
         const int qx = (int)(((float)x + 0.5f) * rcpW);
         const int wo = x - qx * p.Wo;
@@ -187,16 +171,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
             ahw[i] = (m < p.M) ? ((hi0 << 16) | (wi0 & 0xffff)) : (int)0x80000000;
         }
     }
-#else
-    // table entries of this thread's rows (rows >= M lie beyond num_records and read as (0, 0): no valid tap)
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 rinfo[(CONCAT || KS == 3) ? AP : 1];
-    if (CONCAT || KS == 3) {
-        const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.rowtab), 0, p.rowtab_bytes, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < AP; ++i) rinfo[i] = __builtin_amdgcn_raw_buffer_load_b64(rst, (int)((unsigned)(m0 + i * RP + lrow) * 8u), 0, 0);
-    }
-#endif
     unsigned boff[BP];  // byte offset of this lane's piece of weight row n, k = 0
 #pragma unroll
     for (int j = 0; j < BP; ++j) boff[j] = (unsigned)((n0 + j * RP + lrow) * p.K + lchunk) * 4u;
@@ -215,65 +189,52 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
     int tap = 0;
     int c0 = 0;
     int cend = CK;            // end of the current channel chunk (classic order: Cin)
-    constexpr int taps = KS * KS;
+    const int taps = p.ksize * p.ksize;
     unsigned avoff[AP];                  // voffset of this lane's piece for the current tap (or OOB0)
     unsigned okmask[CONCAT ? 1 : AP];    // !CONCAT: bit t = tap t of this row lies inside the image
     unsigned abase4[CONCAT ? 1 : AP];    // !CONCAT: byte offset of this lane's piece of the row at tap (0, 0), channel 0
     unsigned avoff1[CONCAT ? AP : 1];    // CONCAT: same for src1
     auto set_tap = [&]() {
-        if (!CONCAT) {
+        if (CONCAT) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)(aoff[i] + lchunk) * 4u;
+                avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)(aoff1[i] + lchunk) * 4u;
+            }
+        } else {
             // 4 vector instructions per row (bit test, compare, add, select): with the chunk-major K order this runs every
             // CK / 32 K tiles, and vector ALU time is lost MFMA time
-            const int u = tap / KS, v = tap - u * KS;
+            const int u = tap / p.ksize, v = tap - u * p.ksize;
             const unsigned toff4 = (unsigned)((u * p.W + v) * p.Cin) * 4u;
 #pragma unroll
             for (int i = 0; i < AP; ++i) avoff[i] = ((okmask[i] >> tap) & 1u) ? abase4[i] + toff4 : OOB0;
         }
     };
-#ifdef Y3_AB_ARITH_PROLOGUE
-    if (CONCAT) {
-#pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            avoff[i] = (ahw[i] < 0) ? OOB0 : (unsigned)(aoff[i] + lchunk) * 4u;
-            avoff1[i] = (ahw[i] < 0) ? OOB1 : (unsigned)(aoff1[i] + lchunk) * 4u;
-        }
-    } else {
+    if (!CONCAT) {
         // per row: bit t of okmask = tap t reads inside the image (rows >= M: no bit set); byte offset of the lane's piece at tap 0
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             unsigned mk = 0;
             if (ahw[i] >= 0 || (ahw[i] >> 16) != -32768) {
                 const int hi0 = ahw[i] >> 16, wi0 = (int)(short)(ahw[i] & 0xffff);
-                if (KS == 3) {
+                if (p.ksize == 3) {
+                    // closed form of the loop below: row u contributes bits 3u..3u+2, column v bit v of each row.  With the SIMD full
+                    // of 64-cycle MFMAs every vector instruction of a prologue waits ~one MFMA for its issue slot
+                    // (tools/phase_stamps.py --dtype f32: 32 us from entry to the first fetch): six compares instead of two nested loops
                     const unsigned H = (unsigned)p.H, W = (unsigned)p.W;
                     const unsigned rm = ((unsigned)hi0 < H ? 7u : 0u) | ((unsigned)(hi0 + 1) < H ? 56u : 0u) | ((unsigned)(hi0 + 2) < H ? 448u : 0u);
                     const unsigned cm = ((unsigned)wi0 < W ? 1u : 0u) | ((unsigned)(wi0 + 1) < W ? 2u : 0u) | ((unsigned)(wi0 + 2) < W ? 4u : 0u);
                     mk = rm & (cm * 73u);
                 } else {
-                    mk = 1u;
+                    for (int u = 0; u < p.ksize; ++u)
+                        for (int v = 0; v < p.ksize; ++v)
+                            if ((unsigned)(hi0 + u) < (unsigned)p.H && (unsigned)(wi0 + v) < (unsigned)p.W) mk |= 1u << (u * p.ksize + v);
                 }
             }
             okmask[i] = mk;
             abase4[i] = (unsigned)(aoff[i] + lchunk) * 4u;
         }
     }
-#else
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-        if (CONCAT) {
-            const bool live = (unsigned)(m0 + i * RP + lrow) < (unsigned)p.M;   // (a row beyond M would read pixel 0 of both sources: harmless, but keep the zeros)
-            avoff[i] = live ? (rinfo[i][0] * (unsigned)p.C0 + (unsigned)lchunk) * 4u : OOB0;
-            avoff1[i] = live ? (rinfo[i][1] * (unsigned)C1 + (unsigned)lchunk) * 4u : OOB1;
-        } else if (KS == 3) {
-            abase4[i] = (rinfo[i][0] * (unsigned)p.Cin + (unsigned)lchunk) * 4u;
-            okmask[i] = rinfo[i][1];
-        } else {   // single-source 1x1: row m is pixel m
-            const unsigned m = (unsigned)(m0 + i * RP + lrow);
-            abase4[i] = (m * (unsigned)p.Cin + (unsigned)lchunk) * 4u;
-            okmask[i] = m < (unsigned)p.M ? 1u : 0u;
-        }
-    }
-#endif
     set_tap();
 
     f32x4 ra[AP], rb[BP];
@@ -302,7 +263,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                 cend += CK;
             }
             c0 = cend - CK;
-            set_tap();
+            if (!CONCAT) set_tap();
         }
         kglob = tap * p.Cin + c0;
     };
@@ -330,7 +291,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
                 cend += CK;
             }
             c0 = cend - CK;
-            set_tap();
+            if (!CONCAT) set_tap();
         }
         kglob = tap * p.Cin + c0;
     };
@@ -509,8 +470,6 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {0, 0, 0, 0},                                        // 25: retired id
     {64, 128, 4, 2}, {64, 64, 4, 2}, {128, 128, 4, 2}, {128, 64, 4, 2}, {256, 32, 4, 2},  // 26..30: LDS-DMA loads
     {64, 128, 4, 1}, {64, 64, 4, 1},                     // 31, 32: LDS-DMA, single stage
-    // 33..37: persistent workgroups, operand ring across tile boundaries, table-driven row state (conv_f32p.hip)
-    {64, 128, 4, 2, 1}, {64, 64, 4, 2, 1}, {128, 64, 8, 2, 1}, {128, 128, 4, 2, 1}, {128, 128, 8, 2, 1},
 };
 
 #ifdef Y3_PHASE_STAMPS
@@ -525,14 +484,14 @@ TileInfo conv_tile_info(int tile) { return kTiles[(tile >= 0 && tile < TILE_COUN
 
 bool conv_tile_built(int tile) { return tile >= 0 && tile < TILE_COUNT && kTiles[tile].bm > 0; }
 
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int MINW, int DMA, int KS>
-static hipError_t launch_ks(const ConvArgs &a_in, hipStream_t s)
+template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int MINW = 1, int DMA = 0>
+static hipError_t launch_k(const ConvArgs &a_in, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     ConvArgs a = a_in;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.CoutPad / BN;
     const size_t lds = STAGES * (size_t)(BM + BN) * (DMA ? BK : LDS_ROW_PADDED) * sizeof(float);
-    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, MINW, DMA, KS>;
+    auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, MINW, DMA>;
     static LdsAttrOnce attr;  // per instantiation
     if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
     int grid = tilesM * tilesN;
@@ -545,20 +504,6 @@ static hipError_t launch_ks(const ConvArgs &a_in, hipStream_t s)
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
-}
-
-template <int TM, int TN, int WR, int WC, bool CONCAT, int STAGES, int MINW = 1, int DMA = 0>
-static hipError_t launch_k(const ConvArgs &a, hipStream_t s)
-{
-#ifndef Y3_AB_ARITH_PROLOGUE
-    if ((CONCAT || a.ksize == 3) && (!a.rowtab || a.rowtab_bytes < (unsigned)a.M * 8u)) return hipErrorInvalidValue;   // y3_net_plan builds the row tables
-#endif
-    if constexpr (CONCAT) {
-        return launch_ks<TM, TN, WR, WC, true, STAGES, MINW, DMA, 1>(a, s);
-    } else {
-        if (a.ksize == 1) return launch_ks<TM, TN, WR, WC, false, STAGES, MINW, DMA, 1>(a, s);
-        return launch_ks<TM, TN, WR, WC, false, STAGES, MINW, DMA, 3>(a, s);
-    }
 }
 
 template <int TM, int TN, int WR, int WC, int MINW1 = 1>
@@ -575,7 +520,6 @@ static hipError_t launch_t(const ConvArgs &a, int stages, hipStream_t s)
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
 {
     if (!conv_tile_built(tile)) return hipErrorInvalidValue;
-    if (kTiles[tile].pers) return launch_conv_f32_pers(a, tile, s);
     const int stages = kTiles[tile].stages;
     switch (tile) {
         case 0: case 6: return launch_t<2, 2, 2, 2>(a, stages, s);    // 128x128, 4 waves

@@ -130,13 +130,6 @@ struct y3_net {
     // y3_net_plan for max_batch images and Y3_MAX_OUTPUT_BOXES rows, so y3_net_detect itself only enqueues work
     void *det_buf = nullptr;
     size_t det_bytes = 0;
-    // persistent fp32 tiles (conv_f32p.hip): per-output-row tables, one per distinct conv geometry, built by y3_net_plan for
-    // max_batch images (a lane of nb images uses the first nb * Ho * Wo rows)
-    struct RowTab { int H, W, stride, size, up0, concat; void *dev; size_t rows; };
-    std::vector<RowTab> rowtabs;
-    std::vector<int> conv_rowtab;  // per conv slot: index into rowtabs or -1
-    int *pers_ctr = nullptr;       // tile cursors of the persistent tiles: 16 ints per lane, zeroed at plan time, returned to zero by every launch
-    int pers_wg_per_cu = 0;        // y3_net_set_persistent_slots: cap on resident workgroups per CU of the persistent tiles (0: occupancy query)
     int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 (+ the 1x1 after them) as one kernel when the graph allows it; 2 = conv0 + conv1 only
     bool stem_mode_set = false;    // y3_net_set_stem_fusion was called (the Y3_STEM_MODE tool override then stays out)
     bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
@@ -164,11 +157,6 @@ void free_plan(y3_net *n)
     if (n->det_buf) (void)hipFree(n->det_buf);
     n->det_buf = nullptr;
     n->det_bytes = 0;
-    if (n->pers_ctr) (void)hipFree(n->pers_ctr);
-    n->pers_ctr = nullptr;
-    for (auto &t : n->rowtabs) (void)hipFree(t.dev);
-    n->rowtabs.clear();
-    n->conv_rowtab.clear();
     for (void *p : n->blocks) (void)hipFree(p);
     n->blocks.clear();
     n->tdev.assign(n->tensors.size(), nullptr);
@@ -699,13 +687,6 @@ y3_status y3_net_set_xcd_mode(y3_net *net, int mode)
     return Y3_OK;
 }
 
-y3_status y3_net_set_persistent_slots(y3_net *net, int workgroups_per_cu)
-{
-    if (!net || workgroups_per_cu < 0) return fail(Y3_ERR_INVALID, "y3_net_set_persistent_slots: bad argument");
-    net->pers_wg_per_cu = workgroups_per_cu;
-    return Y3_OK;
-}
-
 y3_status y3_net_set_early_chunk(y3_net *net, int n_convs, int chunk_images)
 {
     if (!net || n_convs < 0 || chunk_images < 0) return fail(Y3_ERR_INVALID, "y3_net_set_early_chunk: bad argument");
@@ -732,66 +713,6 @@ static y3_status ensure_lanes(y3_net *net)
     for (int i = 0; i < Y3_MAX_LANES; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&net->lane_stream[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&net->join_ev[i], hipEventDisableTiming));
-    }
-    return Y3_OK;
-}
-
-// Row tables of the persistent fp32 tiles: for output row m = (b, ho, wo) of a conv
-//   3x3 (stride 1 or 2, pad 1 / top-left pad):  {(b*H + ho*s - 1)*W + wo*s - 1  [pixel index of tap (0,0), may be negative],
-//                                               bit 3u+v set iff tap (u, v) reads inside the image}
-//   1x1 over up(src0) (+) src1:                 {pixel index in src0 (through the nearest x2 up-sampling), pixel index in src1}
-// (reference semantics: core/parse_model.py:31-35 padding, :72 UpSampling2D, :134 Concatenate; the arithmetic conv_f32.hip does
-// per workgroup with ~260 vector instructions).  Single-source 1x1 convs need none (row m is pixel m).
-static y3_status build_row_tables(y3_net *net)
-{
-    net->conv_rowtab.assign(net->convs.size(), -1);
-    if (net->dtype != Y3_DTYPE_F32) return Y3_OK;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&net->pers_ctr), Y3_MAX_LANES * 16 * sizeof(int)));
-    HIP_TRY(hipMemset(net->pers_ctr, 0, Y3_MAX_LANES * 16 * sizeof(int)));
-    for (size_t ci = 0; ci < net->convs.size(); ++ci) {
-        const ConvSlot &c = net->convs[ci];
-        const y3_conv_desc &d = c.d;
-        if (c.first_layer || (d.size == 1 && d.src1 < 0)) continue;
-        const int H = net->image_size / d.in_div, Ho = net->image_size / d.out_div;
-        const int concat = d.src1 >= 0 ? 1 : 0;
-        int found = -1;
-        for (size_t t = 0; t < net->rowtabs.size(); ++t) {
-            const auto &r = net->rowtabs[t];
-            if (r.H == H && r.W == H && r.stride == d.stride && r.size == d.size && r.up0 == d.src0_upsample && r.concat == concat) found = (int)t;
-        }
-        if (found < 0) {
-            const size_t rows = (size_t)net->max_batch * Ho * Ho;
-            std::vector<int32_t> tab(rows * 2);
-            size_t m = 0;
-            for (int b = 0; b < net->max_batch; ++b)
-                for (int ho = 0; ho < Ho; ++ho)
-                    for (int wo = 0; wo < Ho; ++wo, ++m) {
-                        if (concat) {
-                            const int H0 = d.src0_upsample ? H / 2 : H;
-                            const int h0 = d.src0_upsample ? ho / 2 : ho, w0 = d.src0_upsample ? wo / 2 : wo;
-                            tab[2 * m] = (b * H0 + h0) * H0 + w0;
-                            tab[2 * m + 1] = (b * H + ho) * H + wo;
-                        } else {
-                            const int hi0 = ho * d.stride - 1, wi0 = wo * d.stride - 1;
-                            int mask = 0;
-                            for (int u = 0; u < 3; ++u)
-                                for (int v = 0; v < 3; ++v)
-                                    if (hi0 + u >= 0 && hi0 + u < H && wi0 + v >= 0 && wi0 + v < H) mask |= 1 << (3 * u + v);
-                            tab[2 * m] = (b * H + hi0) * H + wi0;
-                            tab[2 * m + 1] = mask;
-                        }
-                    }
-            void *dev = nullptr;
-            HIP_TRY(hipMalloc(&dev, rows * 8 + 256));
-            hipError_t e = hipMemcpy(dev, tab.data(), rows * 8, hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                (void)hipFree(dev);
-                return fail(Y3_ERR_HIP, "row table upload: %s", hipGetErrorString(e));
-            }
-            net->rowtabs.push_back({H, H, d.stride, d.size, d.src0_upsample, concat, dev, rows});
-            found = (int)net->rowtabs.size() - 1;
-        }
-        net->conv_rowtab[ci] = found;
     }
     return Y3_OK;
 }
@@ -899,10 +820,6 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
         net->tblock[t] = pool[pick].bytes;
     }
     if (y3_status st = ensure_lanes(net); st != Y3_OK) return st;
-    if (y3_status st = build_row_tables(net); st != Y3_OK) {
-        free_plan(net);
-        return st;
-    }
     {   // Y3_STEM_MODE (tools: same-process-tree A/B of the stem forms) overrides the default, not an explicit setter call
         static const int env = [] { const char *e = getenv("Y3_STEM_MODE"); return e ? atoi(e) : -1; }();
         if (env >= 0 && env <= 2 && !net->stem_mode_set) net->stem_mode = env;
@@ -1034,18 +951,6 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.dst_bytes = (unsigned)bytes(d.dst);
             a.xcd_gn = 0;
             a.k_chunk = 0;
-            a.rowtab = nullptr;
-            a.rowtab_bytes = 0;
-            a.pers_wg_per_cu = net->pers_wg_per_cu;
-            {
-                static const int env = [] { const char *e = getenv("Y3_PERS_STAGGER"); return e ? atoi(e) : 100; }();   // tools: A/B of the start stagger
-                a.pers_stagger = env;
-            }
-            a.pers_ctr = net->pers_ctr ? net->pers_ctr + 16 * lane : nullptr;
-            if (o.index < (int)net->conv_rowtab.size() && net->conv_rowtab[o.index] >= 0) {
-                a.rowtab = net->rowtabs[net->conv_rowtab[o.index]].dev;
-                a.rowtab_bytes = (unsigned)((size_t)nb * (net->image_size / d.out_div) * (net->image_size / d.out_div) * 8);
-            }
             a.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : (net->clk_conv == -2 && net->clk_stamps) ? net->clk_stamps + 8 * o.index : nullptr;   // fp32 MFMA kernel and stem only
             if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if ((net->stem_fused && oi == 0) || (net->stem_conv2 && oi == 2)) {   // runs inside conv1's launch (fused stem)

@@ -29,15 +29,6 @@ struct ConvArgs {
     // fp32 tile order: 0 = every XCD takes a contiguous run of tiles (N fastest); gn in {1,2,4,8} = the XCDs form
     // an (8/gn) x gn grid over the (M-tile, N-tile) matrix (see conv_f32.hip)
     int xcd_gn;
-    // persistent fp32 tiles (conv_f32p.hip): per output row m an int2 built at plan time -- 3x3 convs: {pixel index of tap (0,0)
-    // in src0 (may be negative), 9-bit tap-validity mask}; concat convs: {pixel index in src0, pixel index in src1}; unused by
-    // single-source 1x1 convs.  rowtab_bytes = 8 * M of THIS launch (rows beyond it read as zeros through the bounds check).
-    const void *rowtab;
-    unsigned rowtab_bytes;
-    int *pers_ctr;         // [9] ints, zero between launches: 8 per-XCD tile cursors + the count of workgroups that have left (owned by the net, one set per lane)
-    int pers_stagger;      // start stagger of the workgroups sharing a CU, in % of one tile's matrix time per group (0: none)
-    int pers_groups;       // filled by the launcher: workgroups per CU of a full grid (1: no stagger)
-    int pers_wg_per_cu;    // > 0: cap on resident workgroups per CU of a persistent launch (tools); 0 = what the occupancy query says
     int k_chunk;           // fp32 MFMA kernel, 3x3 convs: > 0 walks K chunk-major, k_chunk input channels at a time (conv_f32.hip); 0: tap-major
     // measurement only (y3_net_measure_sclk): when non-null, thread 0 of the middle workgroup stores {s_memtime, s_memrealtime}
     // at its entry and after its epilogue -> the shader clock held while that workgroup ran.  Null in every product launch.
@@ -59,13 +50,12 @@ inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes)
 }
 
 // tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
-static constexpr int TILE_COUNT = 38;  // 20..22, 25: retired ids (the timing-only probes of rounds 1-2); 33..37: persistent form (conv_f32p.hip)
-struct TileInfo { int bm, bn, waves, stages; int pers = 0; };
+static constexpr int TILE_COUNT = 33;  // 20..22, 25: retired ids (the timing-only probes of rounds 1-2)
+struct TileInfo { int bm, bn, waves, stages; };
 TileInfo conv_tile_info(int tile);
 bool conv_tile_built(int tile);        // false: retired id
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
-hipError_t launch_conv_f32_pers(const ConvArgs &a, int tile, hipStream_t s);   // tiles 33..37 (called by launch_conv_f32)
 // first layer: 3x3 stride-1 conv with Cin=3 (direct, VALU)
 hipError_t launch_conv_first_f32(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
 

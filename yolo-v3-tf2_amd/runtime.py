@@ -133,10 +133,6 @@ class Net:
         the Darknet-53 stem and the plan is fp32 or bf16 without keep_activations).  2: conv0 + conv1 only."""
         check(self.lib.y3_net_set_stem_fusion(self._h, int(on)), "y3_net_set_stem_fusion")
 
-    def set_persistent_slots(self, workgroups_per_cu: int):
-        """Resident workgroups per CU of the persistent fp32 tiles 33..37 (0 = the occupancy query's answer)."""
-        check(self.lib.y3_net_set_persistent_slots(self._h, int(workgroups_per_cu)), "y3_net_set_persistent_slots")
-
     def set_early_chunk(self, n_convs: int, chunk_images: int):
         """Before plan(): the first n_convs convs run chunk_images images at a time (their activations then stay in the
         Infinity Cache between producer and consumer); 0, 0 switches it off."""
