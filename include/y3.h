@@ -247,6 +247,14 @@ y3_status y3_pack_detections(const float *bboxes_dev, const int64_t *class_idx_d
                              const int32_t *selected_idx_dev, const int32_t *num_valid_dev, int batch, int n,
                              int max_out, void *packed_dev, void *stream);
 
+/* Conv program + decode in one call: images -> (bboxes [B,N,4], class_indices [B,N] int64, scores [B,N]), i.e.
+ * model(inputs) -> yolo_decode -> argmax / score (reference: inference.py:109-117 up to the NMS; core/yolo_decode_layer.py:15-36,
+ * core/yolo_nms.py:18-24).  Where the graph allows it (every head a 1x1 conv + bias writing its grid; fp32 and bf16 plans) the
+ * three head convs decode their own output tiles while these are still on chip, and the [B,g,g,3*(5+nc)] grids are neither
+ * written nor read back; otherwise it is y3_net_forward into net-owned scratch + y3_yolo_decode_scores.  Either way the
+ * results are bit-identical to that composed route.  Outputs are caller-owned device buffers; bboxes 16-byte aligned. */
+y3_status y3_net_forward_decode(y3_net *net, const float *images_dev, int batch, const float *anchors_host, float *bboxes_dev,
+                                int64_t *class_idx_dev, float *scores_dev, void *stream);
 /* ------------------------------------------------------------------------------------------
  * The whole path in one call: Model(inputs, nms_output).predict(batch) followed by the per-image gather
  * (reference: inference.py:109-117, 125-128, 21-28) = y3_net_forward -> y3_yolo_decode_scores -> y3_nms_padded ->

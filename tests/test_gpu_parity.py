@@ -727,6 +727,47 @@ def test_detect_single_call_equals_composed_pipeline(rt, program, weights, ancho
         net.detect(x, anchors, 0, 0.5, 0.05)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("S,B,lanes", [(96, 3, 1), (128, 5, 2), (416, 2, 1)])
+def test_forward_decode_fused_heads_equal_the_composed_route(rt, program, weights, anchors, mode, S, B, lanes):
+    """y3_net_forward_decode: the three head convs (1x1 + bias, 255 channels) decode their own output tiles -- sigmoid / exp *
+    anchor / grid offset, class arg-max, score -- and never write the grids.  Boxes, class indices and scores must be BIT-
+    IDENTICAL to y3_net_forward + y3_yolo_decode_scores on the same plan (fp32: conv_head.hip repeats the k order of the
+    stand-alone launch; bf16: the fused epilogue decodes the very fp32 tile the grid store would have written), for sub-batch
+    lanes too, on ragged last tiles (3 x 3^2 = 27 pixels of a 64-pixel tile), and on a second call."""
+    from yolo_v3_tf2_amd import _lib
+    dt = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16}[mode]
+    x = _cuda(np.random.default_rng(41).random((B, S, S, 3), dtype=np.float32))
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(B, S, dt)
+    net.set_lanes(lanes)
+    grids = net.forward(x)
+    bb, cc, ss = rt.yolo_decode_scores(grids, anchors, 80)
+    for _ in range(2):
+        fb, fc, fs = net.forward_decode(x, anchors)
+        torch.cuda.synchronize()
+        assert torch.equal(fb, bb) and torch.equal(fc, cc) and torch.equal(fs, ss)
+    # a smaller batch on the same plan
+    fb1, fc1, fs1 = net.forward_decode(x[1:2].contiguous(), anchors)
+    assert torch.equal(fb1, bb[1:2]) and torch.equal(fc1, cc[1:2]) and torch.equal(fs1, ss[1:2])
+
+
+def test_forward_decode_falls_back_when_heads_cannot_decode(rt, program, weights, anchors, monkeypatch):
+    """keep_activations plans (and the plane-split modes) take the composed route inside y3_net_forward_decode: same results."""
+    from yolo_v3_tf2_amd import _lib
+    x = _cuda(np.random.default_rng(42).random((2, 96, 96, 3), dtype=np.float32))
+    for dt, keep in ((_lib.Y3_DTYPE_F32, True), (_lib.Y3_DTYPE_F32X2, False)):
+        net = rt.Net(program)
+        net.load_weights(weights)
+        net.keep_activations(keep)
+        net.plan(2, 96, dt)
+        grids = net.forward(x)
+        bb, cc, ss = rt.yolo_decode_scores(grids, anchors, 80)
+        fb, fc, fs = net.forward_decode(x, anchors)
+        assert torch.equal(fb, bb) and torch.equal(fc, cc) and torch.equal(fs, ss)
+
+
 def test_full_size_batch_properties(rt, program, weights, anchors):
     """BASELINE size (batch 64, 416x416) through size-independent properties: (1) determinism, (2) batch
     independence -- image i of the 64-batch equals the same image run alone, bit for bit (the per-pixel K order does

@@ -1,10 +1,10 @@
 #!/bin/bash
-# visit 4f: bf16 stem with the 1x1 third layer (phase 3): tests, then bench A/B (Y3_STEM_MODE env is read by nothing: A/B through git stash is not possible on the box, so bench both modes via tools/ab_stem_mode.py)
+# visit 4f: fp32 lanes sweep and a steady-state re-tune of the 64 x 416^2 table on the round-4 library
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "stem or bf16" > gpurun_out/4f_tests.log 2>&1 || { tail -40 gpurun_out/4f_tests.log; exit 1; }
-tail -2 gpurun_out/4f_tests.log
-for rep in 1 2; do
-  timeout -k 10 300 python bench.py --dtype bf16 --batch 128 --graph --steps 30 --warmup 10 --no-cpu-baseline > gpurun_out/4f_bf16_$rep.log 2>&1 || { tail -20 gpurun_out/4f_bf16_$rep.log; exit 1; }
-  echo "rep=$rep $(tail -n 1 gpurun_out/4f_bf16_$rep.log | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"
-done
+timeout -k 10 400 python tools/lanes_sweep.py --dtype f32 --lanes 1,2,3,4 > gpurun_out/r4f_lanes_sweep_f32.txt 2>&1 || { tail -20 gpurun_out/r4f_lanes_sweep_f32.txt; exit 1; }
+grep -v amdgpu gpurun_out/r4f_lanes_sweep_f32.txt | tail -8
+cp yolo-v3-tf2_amd/tuning/f32_b64_s416.json gpurun_out/r4f_f32_b64_s416_before.json
+timeout -k 10 1000 python tools/tune_steady.py --dtype f32 --batch 64 --steps 15 --write f32_b64_s416.json > gpurun_out/r4f_tune_steady_f32.txt 2>&1 || { tail -20 gpurun_out/r4f_tune_steady_f32.txt; exit 1; }
+grep -v "keeps tile" gpurun_out/r4f_tune_steady_f32.txt | grep -v amdgpu
+cp yolo-v3-tf2_amd/tuning/f32_b64_s416.json gpurun_out/r4f_f32_b64_s416.json

@@ -1,15 +1,18 @@
 #!/bin/bash
-# visit 4h: bf16 stem with conv0 on split-bf16 operands (hi + lo, 3 MFMAs per product): tests, then same-box A/B against the
-# fp32-MFMA conv0 build (lib/liby3hip_oldstem.so)
+# visit 4h: kernel trace of the fused-decode bench (fp32, bf16) -- how long do the head launches take against the composed route?
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "stem or bf16" > gpurun_out/4h_tests.log 2>&1 || { tail -40 gpurun_out/4h_tests.log; exit 1; }
-tail -2 gpurun_out/4h_tests.log
-for rep in 1 2 3; do
-  for l in new old; do
-    if [ $l = old ]; then export Y3_LIB_PATH=$PWD/yolo-v3-tf2_amd/lib/liby3hip_oldstem.so; else unset Y3_LIB_PATH; fi
-    timeout -k 10 300 python bench.py --dtype bf16 --batch 128 --graph --steps 30 --warmup 10 --no-cpu-baseline > gpurun_out/4h_bf16_${l}_$rep.log 2>&1 || { tail -20 gpurun_out/4h_bf16_${l}_$rep.log; exit 1; }
-    echo "$l rep=$rep $(tail -n 1 gpurun_out/4h_bf16_${l}_$rep.log | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"
-  done
+export TMPDIR=/tmp
+for f in 1 0; do
+  export Y3_FUSE_DECODE=$f
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/r4h_f32_fuse$f -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-sclk --parity-images 0 > gpurun_out/r4h_f32_fuse$f.log 2>&1 || { tail -5 gpurun_out/r4h_f32_fuse$f.log; exit 1; }
+  python3 - <<PY
+import csv, glob, collections
+f = glob.glob("gpurun_out/r4h_f32_fuse$f/**/run_kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+for r in rows:
+    n = r["Name"]
+    if "head" in n or "decode" in n or "nms" in n or ("ELi1ELi" in n and False):
+        print("fuse$f", n[:70], r["Calls"], r["AverageNs"])
+PY
 done
-unset Y3_LIB_PATH

@@ -113,6 +113,7 @@ SYMBOLS = {
     "y3_nms_padded": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "y3_pack_detections": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "y3_crc32c": (C.c_uint32, [_vp, C.c_size_t]),
+    "y3_net_forward_decode": (_i, [_vp, _vp, _i, _fp, _vp, _vp, _vp, _vp]),
     "y3_net_detect": (_i, [_vp, _vp, _i, _fp, _i, C.c_float, C.c_float, _vp, _vp, _vp]),
     "y3_comm_get_unique_id": (_i, [_vp]),
     "y3_comm_init_rank": (_i, [_vp, _i, _i, C.POINTER(_vp)]),

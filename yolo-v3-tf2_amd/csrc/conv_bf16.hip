@@ -10,6 +10,7 @@
 //     thread converts 8 consecutive channels (+ bf16 residual) and issues ONE 16-byte store -> full 128-B lines.
 #include <type_traits>
 
+#include "decode_box.h"
 #include "y3_kernels.h"
 
 namespace y3 {
@@ -402,11 +403,17 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
             }
             __syncthreads();
             float *dst = static_cast<float *>(p.dst);
-            for (int idx = tid; idx < EROWS * BN; idx += NT) {
-                const int r = idx / BN, col = idx - r * BN;
-                const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31), n = n0 + col;
-                if (m < p.M && n < p.Cout) dst[(size_t)m * p.Cout + n] = C[r * CROW + col];
+            if (dst != nullptr) {
+                for (int idx = tid; idx < EROWS * BN; idx += NT) {
+                    const int r = idx / BN, col = idx - r * BN;
+                    const int m = m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31), n = n0 + col;
+                    if (m < p.M && n < p.Cout) dst[(size_t)m * p.Cout + n] = C[r * CROW + col];
+                }
             }
+            // detection head with its decode fused in (y3_net_forward_decode; the launcher guarantees a tile that spans all
+            // 3 * (5 + nc) channels): the EROWS pixels of this pass are decoded from the fp32 tile in LDS, same body as decode.hip
+            if (p.dec.boxes != nullptr)
+                decode_rows_from_lds<NT>(C, CROW, EROWS, [&](int r) { return m0 + (r >> 5) * 32 * TM + i * 32 + (r & 31); }, p.M, p.dec);
         }
     }
 }
@@ -481,6 +488,8 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
 {
     if (!conv_bf16_tile_built(tile)) return hipErrorInvalidValue;
     const TileInfo t = kTilesBf16[tile];
+    if (a.dec.boxes != nullptr && (!out_f32 || t.bn < a.CoutPad)) return hipErrorInvalidValue;   // a fused head needs all its channels in one tile
+    if (a.dst == nullptr && a.dec.boxes == nullptr) return hipErrorInvalidValue;
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
     switch (tile) {
         case 0: return launch_tb<2, 2, 2, 2, 64>(a, out_f32, s);

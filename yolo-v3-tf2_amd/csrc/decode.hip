@@ -10,6 +10,7 @@
 // written back through LDS so that the [B,N,nc] store is coalesced.
 // Arithmetic: sigmoid(x) = 1/(1+exp(-x)), true divisions, fp32, no contraction (-ffp-contract=off).
 #include "y3_kernels.h"
+#include "decode_box.h"
 
 namespace y3 {
 
@@ -18,8 +19,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int DEC_BOXES = 64;    // boxes per workgroup
 static constexpr int DEC_LANES = 4;     // lanes per box
 static constexpr int DEC_THREADS = DEC_BOXES * DEC_LANES;
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 struct DecodeLaunch {
     DecodeArgs a;
@@ -61,51 +60,15 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeLaunch 
     const int row = cell / g, col = cell - row * g;
     const long long out_row = (long long)b * L.a.N + L.a.off[s] + r;
     float *t = lds + jj * F;
-    // grid = meshgrid(range(W), range(H)): (...,0) = col, (...,1) = row; divisor cast([H,W]) (square grid).
-    // lane 0: x, lane 1: y, lane 2: w, lane 3: h
-    float v;
-    if (q < 2)
-        v = (sigmoidf_(t[q]) + (float)(q == 0 ? col : row)) / (float)g;
-    else
-        v = expf(t[q]) * L.a.anchors[s][a][q - 2];
-    const int base = (tid & 63) & ~3;             // first lane of this box inside the wave
-    const float x = __shfl(v, base + 0), y = __shfl(v, base + 1), w = __shfl(v, base + 2), h = __shfl(v, base + 3);
-    float c = 0.0f;
-    if (q == 0) {
-        f32x4 bb;
-        bb[0] = x - w / 2;
-        bb[1] = y - h / 2;
-        bb[2] = x + w / 2;
-        bb[3] = y + h / 2;
-        c = sigmoidf_(t[4]);
-        if (live) {
-            *reinterpret_cast<f32x4 *>(bboxes + out_row * 4) = bb;
-            if (conf) conf[out_row] = c;
-        }
-    }
-    // classes q, q+4, ...: first maximum of the lane's own subsequence, then of the four lanes (ties -> lowest index,
-    // like tf.argmax over the whole row)
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int k = q; k < L.a.nc; k += DEC_LANES) {
-        const float pk = sigmoidf_(t[5 + k]);
-        if (WRITE_PROBS && live) t[5 + k] = pk;
-        if (k == q || pk > best) {
-            best = pk;
-            besti = k;
-        }
-    }
-    if (WRITE_SCORES) {
-#pragma unroll
-        for (int m = 1; m < DEC_LANES; m <<= 1) {
-            const float ob = __shfl_xor(best, m);
-            const int oi = __shfl_xor(besti, m);
-            if (ob > best || (ob == best && oi < besti)) {
-                best = ob;
-                besti = oi;
-            }
-        }
-        if (q == 0 && live) {
+    // lane 0: x, lane 1: y, lane 2: w, lane 3: h; classes q, q + 4, ... (decode_box.h: the body the fused head convs share)
+    f32x4 bb;
+    float c, best;
+    int besti;
+    decode_box_lanes<WRITE_PROBS, WRITE_SCORES>(t, q, tid & 63, L.a.nc, g, row, col, q >= 2 ? L.a.anchors[s][a][q - 2] : 0.0f, live, bb, c, best, besti);
+    if (q == 0 && live) {
+        *reinterpret_cast<f32x4 *>(bboxes + out_row * 4) = bb;
+        if (conf) conf[out_row] = c;
+        if (WRITE_SCORES) {
             cls[out_row] = (int64_t)besti;
             scores[out_row] = c * best;
         }

@@ -130,6 +130,9 @@ struct y3_net {
     // y3_net_plan for max_batch images and Y3_MAX_OUTPUT_BOXES rows, so y3_net_detect itself only enqueues work
     void *det_buf = nullptr;
     size_t det_bytes = 0;
+    // y3_net_forward_decode: while set, the three head convs decode their own tiles into these buffers (per scale: first box
+    // index, grid size, anchors) instead of writing grids.  Null outside that call.
+    const y3::DecodeHead *fuse = nullptr;   // [3], in output order
     int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 (+ the 1x1 after them) as one kernel when the graph allows it; 2 = conv0 + conv1 only
     bool stem_mode_set = false;    // y3_net_set_stem_fusion was called (the Y3_STEM_MODE tool override then stays out)
     bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
@@ -952,7 +955,19 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.xcd_gn = 0;
             a.k_chunk = 0;
             a.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : (net->clk_conv == -2 && net->clk_stamps) ? net->clk_stamps + 8 * o.index : nullptr;   // fp32 MFMA kernel and stem only
-            if (!a.src0 || !a.dst) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
+            int head = -1;   // fused decode: which output this conv produces (its grid is then not written)
+            if (net->fuse)
+                for (int k = 0; k < 3; ++k)
+                    if (d.dst == net->outputs[k] && !net->staged[d.dst]) head = k;
+            if (head >= 0) {
+                a.dec = net->fuse[head];
+                a.dec.boxes += (size_t)b0 * a.dec.N * 4;
+                a.dec.cls += (size_t)b0 * a.dec.N;
+                a.dec.scores += (size_t)b0 * a.dec.N;
+                a.dst = nullptr;
+                a.dst_bytes = 0;
+            }
+            if (!a.src0 || (!a.dst && head < 0)) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", o.index);
             if ((net->stem_fused && oi == 0) || (net->stem_conv2 && oi == 2)) {   // runs inside conv1's launch (fused stem)
                 if (ms_out && o.index < n_ms) ms_out[o.index] = 0.0f;
                 continue;
@@ -1013,10 +1028,17 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * 2);
                 const bool out_f32 = is_out(d.dst);
                 if (d.residual >= 0 && out_f32) return fail(Y3_ERR_INVALID, "conv %d: residual on a head output is not supported in bf16 mode", o.index);
-                const int tile = c.tile_bf16 >= 0 ? c.tile_bf16 : choose_tile_bf16(c, a.M, (long long)net->max_batch * a.Ho * a.Wo);
+                int tile = c.tile_bf16 >= 0 ? c.tile_bf16 : choose_tile_bf16(c, a.M, (long long)net->max_batch * a.Ho * a.Wo);
+                if (head >= 0 && y3::conv_bf16_tile_info(tile).bn != 256) {   // a box's logits must meet in one workgroup: all 256 channels in the tile
+                    const bool m16 = tile >= 24 && tile <= 29;                // keep the MFMA shape of the plan's tile: same K grouping, same bits
+                    const bool big = (a.M + 255) / 256 >= 256;                // 256x256 once it fills the chip, else 128x256 (16 waves both)
+                    tile = m16 ? (big ? 24 : 26) : (big ? 17 : 19);
+                }
                 e = y3::launch_conv_bf16(a, tile, out_f32, s);
             } else if (c.first_layer) {
                 e = y3::launch_conv_first_f32(a, c.w_dev, s);
+            } else if (head >= 0) {
+                e = y3::launch_conv_head_decode_f32(a, s);
             } else {
                 const int tile = c.tile >= 0 ? c.tile : choose_tile(c, a.M);
                 if (net->xcd_mode) a.xcd_gn = choose_xcd_gn(c, a, y3::conv_tile_info(tile));
@@ -1406,6 +1428,79 @@ y3_status y3_class_scores(const float *conf_dev, const float *probs_dev, int bat
     return Y3_OK;
 }
 
+// ------------------------------------------------------------------------------------------ forward + decode
+namespace {
+// Can the three heads decode in place?  Each output must come from a 1x1 / stride-1 single-source conv without shortcut whose
+// 3 * (5 + nc) channels fit one 256-wide tile, written straight to the caller-visible grid (not staged), in an fp32 or bf16
+// plan.  Y3_FUSE_DECODE=0 (tools: A/B against the composed route) switches the fusion off.
+bool heads_can_decode(const y3_net *net)
+{
+    static const bool off = [] { const char *e = getenv("Y3_FUSE_DECODE"); return e && e[0] == '0'; }();
+    if (off || net->nclasses <= 0 || (net->dtype != Y3_DTYPE_F32 && net->dtype != Y3_DTYPE_BF16)) return false;
+    if (net->keep_all || net->early_ops > 0 || 3 * (5 + net->nclasses) > 256) return false;
+    for (int k = 0; k < 3; ++k) {
+        const int t = net->outputs[k];
+        if (net->staged[t]) return false;
+        int producers = 0;
+        for (const ConvSlot &c : net->convs) {
+            if (c.d.dst != t) continue;
+            ++producers;
+            if (c.first_layer || c.d.size != 1 || c.d.stride != 1 || c.d.src1 >= 0 || c.d.residual >= 0 || c.d.cin % 64 ||
+                c.d.cout != 3 * (5 + net->nclasses) || c.cout_pad != 256)
+                return false;
+        }
+        if (producers != 1) return false;
+        for (const y3_aux_desc &x : net->aux)
+            if (x.dst == t) return false;
+    }
+    return true;
+}
+}  // namespace
+
+y3_status y3_net_forward_decode(y3_net *net, const float *images_dev, int batch, const float *anchors_host, float *bboxes_dev,
+                                int64_t *class_idx_dev, float *scores_dev, void *stream)
+{
+    if (!net || !images_dev || !anchors_host || !bboxes_dev || !class_idx_dev || !scores_dev || batch <= 0)
+        return fail(Y3_ERR_INVALID, "y3_net_forward_decode: bad argument");
+    if (net->nclasses <= 0) return fail(Y3_ERR_STATE, "y3_net_forward_decode: the net was created without detection heads (nclasses = 0)");
+    if (!net->image_size) return fail(Y3_ERR_STATE, "y3_net_forward_decode: call y3_net_plan first");
+    if (batch > net->max_batch) return fail(Y3_ERR_INVALID, "y3_net_forward_decode: batch %d > planned %d", batch, net->max_batch);
+    if ((uintptr_t)bboxes_dev & 15) return fail(Y3_ERR_INVALID, "y3_net_forward_decode: bboxes not 16-byte aligned");
+    Y3_ENTER_DEVICE(net);
+    int32_t gs[3];
+    size_t gelems[3], n = 0, off[9];
+    detect_layout(net, batch, off, &n, gs, gelems);
+    if (!net->det_buf || net->det_bytes < off[8])
+        return fail(Y3_ERR_STATE, "y3_net_forward_decode: detect scratch not planned (y3_net_plan allocates it)");
+    char *b = static_cast<char *>(net->det_buf);
+    float *grids[3] = {reinterpret_cast<float *>(b + off[0]), reinterpret_cast<float *>(b + off[1]), reinterpret_cast<float *>(b + off[2])};
+    if (!heads_can_decode(net)) {   // composed route: grids into the scratch, then the stand-alone decode
+        y3_status st = y3_net_forward(net, images_dev, batch, grids, stream);
+        if (st != Y3_OK) return st;
+        return y3_yolo_decode_scores(grids, gs, batch, net->nclasses, anchors_host, bboxes_dev, class_idx_dev, scores_dev, stream);
+    }
+    y3::DecodeHead heads[3];
+    int first = 0;
+    for (int k = 0; k < 3; ++k) {
+        heads[k].boxes = bboxes_dev;
+        heads[k].cls = class_idx_dev;
+        heads[k].scores = scores_dev;
+        heads[k].g = gs[k];
+        heads[k].off = first;
+        heads[k].N = (int)n;
+        heads[k].nc = net->nclasses;
+        for (int a = 0; a < 3; ++a) {
+            heads[k].anchors[a][0] = anchors_host[(k * 3 + a) * 2 + 0];
+            heads[k].anchors[a][1] = anchors_host[(k * 3 + a) * 2 + 1];
+        }
+        first += gs[k] * gs[k] * 3;
+    }
+    net->fuse = heads;
+    y3_status st = run(net, images_dev, batch, grids, (hipStream_t)stream, nullptr, 0);
+    net->fuse = nullptr;
+    return st;
+}
+
 // ------------------------------------------------------------------------------------------ nms
 // ------------------------------------------------------------------------------------------ whole pipeline
 y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const float *anchors_host, int max_boxes,
@@ -1425,18 +1520,15 @@ y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const f
     detect_layout(net, batch, off, &n, gs, gelems);
     if (!net->det_buf || net->det_bytes < off[8])
         return fail(Y3_ERR_STATE, "y3_net_detect: detect scratch not planned (y3_net_plan allocates it)");
-    const size_t o_grid0 = off[0], o_grid1 = off[1], o_grid2 = off[2], o_box = off[3], o_cls = off[4], o_score = off[5];
+    const size_t o_box = off[3], o_cls = off[4], o_score = off[5];
     const size_t o_sel = off[6], o_ws = off[7];
     const size_t ws_bytes = y3::nms_workspace_bytes(batch, (int)n);
     char *b = static_cast<char *>(net->det_buf);
-    float *grids[3] = {reinterpret_cast<float *>(b + o_grid0), reinterpret_cast<float *>(b + o_grid1),
-                       reinterpret_cast<float *>(b + o_grid2)};
-    y3_status st = y3_net_forward(net, images_dev, batch, grids, stream);
-    if (st != Y3_OK) return st;
     float *boxes = reinterpret_cast<float *>(b + o_box), *scores = reinterpret_cast<float *>(b + o_score);
     int64_t *cls = reinterpret_cast<int64_t *>(b + o_cls);
     int32_t *sel = reinterpret_cast<int32_t *>(b + o_sel);
-    st = y3_yolo_decode_scores(grids, gs, batch, net->nclasses, anchors_host, boxes, cls, scores, stream);
+    // conv program with the head convs decoding their own tiles (grids neither written nor read back) where the graph allows it
+    y3_status st = y3_net_forward_decode(net, images_dev, batch, anchors_host, boxes, cls, scores, stream);
     if (st != Y3_OK) return st;
     st = y3_nms_padded(boxes, scores, batch, (int)n, max_boxes, iou_threshold, score_threshold, sel, num_valid_dev,
                        b + o_ws, ws_bytes, stream);

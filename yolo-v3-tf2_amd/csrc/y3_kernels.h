@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "decode_box.h"
+
 namespace y3 {
 
 // One fused conv launch: Conv2D [+BN] [+LeakyReLU(0.1)] [+shortcut add], optional
@@ -29,6 +31,9 @@ struct ConvArgs {
     // fp32 tile order: 0 = every XCD takes a contiguous run of tiles (N fastest); gn in {1,2,4,8} = the XCDs form
     // an (8/gn) x gn grid over the (M-tile, N-tile) matrix (see conv_f32.hip)
     int xcd_gn;
+    // head convs only (conv_head.hip, the fp32-output epilogue of conv_bf16.hip): dec.boxes != nullptr -> the launch decodes
+    // its own output tile (y3_net_forward_decode); dst may then be nullptr (the raw grid is not wanted)
+    DecodeHead dec;
     int k_chunk;           // fp32 MFMA kernel, 3x3 convs: > 0 walks K chunk-major, k_chunk input channels at a time (conv_f32.hip); 0: tap-major
     // measurement only (y3_net_measure_sclk): when non-null, thread 0 of the middle workgroup stores {s_memtime, s_memrealtime}
     // at its entry and after its epilogue -> the shader clock held while that workgroup ran.  Null in every product launch.
@@ -56,6 +61,9 @@ TileInfo conv_tile_info(int tile);
 bool conv_tile_built(int tile);        // false: retired id
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
+// 1x1 head conv (Cout = 3 * (5 + nc) <= 256) + bias with yolo_decode + arg-max / score fused in (conv_head.hip)
+bool conv_head_decode_f32_fits(const ConvArgs &a);
+hipError_t launch_conv_head_decode_f32(const ConvArgs &a, hipStream_t s);
 // first layer: 3x3 stride-1 conv with Cin=3 (direct, VALU)
 hipError_t launch_conv_first_f32(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
 

@@ -276,6 +276,25 @@ class Net:
               "y3_net_read_tensor")
         return out
 
+    def forward_decode(self, images: torch.Tensor, anchors):
+        """images -> (bboxes [B,N,4], class_indices [B,N] int64, scores [B,N]): the conv program with the head convs decoding
+        their own tiles (y3_net_forward_decode; reference: model(inputs) -> yolo_decode -> argmax / score).  Same bits as
+        forward() + yolo_decode_scores()."""
+        _need_cuda(images)
+        if images.dtype != torch.float32 or images.dim() != 4 or images.shape[3] != 3:
+            raise Y3Error("images must be float32 [B,S,S,3]")
+        B, S = images.shape[0], images.shape[1]
+        if S != self.image_size or B > self.max_batch:
+            self.plan(max(B, self.max_batch), S)
+        a = np.ascontiguousarray(np.asarray(anchors, np.float32).reshape(3, 3, 2))
+        n = sum(3 * g * g for g in self.grid_sizes())
+        bboxes = torch.empty((B, n, 4), dtype=torch.float32, device=images.device)
+        cls = torch.empty((B, n), dtype=torch.int64, device=images.device)
+        scores = torch.empty((B, n), dtype=torch.float32, device=images.device)
+        check(self.lib.y3_net_forward_decode(self._h, _dev(images), B, _fptr(a), _dev(bboxes), _dev(cls), _dev(scores),
+                                             _lib.stream_ptr()), "y3_net_forward_decode")
+        return bboxes, cls, scores
+
     def detect(self, images: torch.Tensor, anchors, max_boxes: int, iou_threshold: float, score_threshold: float):
         """The whole path in one C call (y3_net_detect): -> (packed [B,max_boxes,7] int32 words, num_valid [B] int32);
         `unpack_detections` splits the rows."""
