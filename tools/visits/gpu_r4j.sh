@@ -1,11 +1,13 @@
 #!/bin/bash
-# visit 4j: bf16 config-5 geometry, eager launches on two lane streams vs the same step replayed from a HIP graph; lanes 2 vs 3
+# visit 4j: bf16 128 x 416^2 bench: table of round 3 / weight-resident kernel on conv3 only / on conv3 + the two 3x3 64->128 @104
 set -o pipefail
 mkdir -p gpurun_out
-for rep in 1 2; do
-  for mode in "--graph" "" "--graph --lanes 3" "--lanes 3" "--graph --lanes 1"; do
-    tag=$(echo "$mode" | tr -d ' -')
-    timeout -k 10 300 python bench.py --dtype bf16 --batch 128 $mode --steps 30 --warmup 10 --no-cpu-baseline > gpurun_out/4j_bf16_${tag}_$rep.log 2>&1 || { tail -20 gpurun_out/4j_bf16_${tag}_$rep.log; exit 1; }
-    echo "[$mode] rep=$rep $(tail -n 1 gpurun_out/4j_bf16_${tag}_$rep.log | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["roofline"]["ms_per_launch"])')"
-  done
+for t in base resident_conv3only resident base resident; do
+  if [ $t = base ]; then unset Y3_TUNING_FILE; else export Y3_TUNING_FILE=$PWD/tools/tables/bf16_b128_s416_$t.json; fi
+  timeout -k 10 400 python bench.py --steps 20 --warmup 5 --dtype bf16 --batch 128 --graph --no-cpu-baseline --parity-images 0 > gpurun_out/r4j_bf16_$t.json 2> gpurun_out/r4j_bf16_$t.err || { tail -20 gpurun_out/r4j_bf16_$t.err; exit 1; }
+  python - <<PY
+import json
+d = json.load(open("gpurun_out/r4j_bf16_$t.json"))
+print("$t", d["value"], d["ms_per_step"], d["roofline"]["ms_per_launch"])
+PY
 done

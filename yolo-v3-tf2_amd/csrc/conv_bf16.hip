@@ -446,6 +446,7 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {128, 256, 8, 32}, {256, 128, 8, 32}, {128, 128, 4, 32},      // 21..23: LDS-DMA with BK = 32, several workgroups per CU
     {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64}, {128, 128, 4, 64}, {128, 64, 4, 64}, {64, 128, 4, 64},  // 24..29: 16x16x32 MFMAs
     {128, 64, 4, 32}, {64, 64, 4, 32},                            // 30, 31: LDS-DMA with BK = 32 for the Cin = 32 / Cout = 64 layer
+    {128, 64, 8, 32},                                             // 32: weight-resident 3x3 / stride 1, Cin = 32 / 64 (conv_res_bf16.hip): 4 x 32 pixels x 64 channels per workgroup tile
 };
 
 #ifdef Y3_PHASE_STAMPS
@@ -491,6 +492,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
     if (a.dec.boxes != nullptr && (!out_f32 || t.bn < a.CoutPad)) return hipErrorInvalidValue;   // a fused head needs all its channels in one tile
     if (a.dst == nullptr && a.dec.boxes == nullptr) return hipErrorInvalidValue;
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
+    if (tile == 32) return (!out_f32 && conv_res_bf16_fits(a)) ? launch_conv_res_bf16(a, s) : hipErrorInvalidValue;
     switch (tile) {
         case 0: return launch_tb<2, 2, 2, 2, 64>(a, out_f32, s);
         case 1: return launch_tb<2, 2, 4, 2, 64>(a, out_f32, s);

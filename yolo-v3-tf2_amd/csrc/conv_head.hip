@@ -22,7 +22,7 @@ namespace {
 constexpr int HBK = 32, HBM = 64, HBN = 256, HNT = 512, HRP = HNT / 8;   // 64 rows per load pass: A in one pass, B in four
 constexpr int HCROW = 257;                                                // floats per row of the output tile in LDS (odd: conflict-free column walks)
 constexpr int HSTAGE = (HBM + HBN) * HBK;                                  // floats of the operand stage
-constexpr size_t HLDS = sizeof(float) * (HBM * HCROW > HSTAGE ? HBM * HCROW : HSTAGE);
+constexpr size_t HLDS = sizeof(float) * (HBM * HCROW > 2 * HSTAGE ? HBM * HCROW : 2 * HSTAGE);   // two operand stages (80 KB), the output tile overlays them: 2 workgroups per CU
 
 __global__ __launch_bounds__(HNT, 2) void conv_head_decode_f32(const ConvArgs p)
 {
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(HNT, 2) void conv_head_decode_f32(const ConvArgs p)
 
     typedef __attribute__((address_space(3))) void *lds_ptr;
     int kglob = 0;
-    auto fetch = [&]() {
-        float *sa = smem + wave * 8 * HBK;   // wave w fills rows [pass * 64 + 8 w, +8)
+    auto fetch = [&](int buf) {
+        float *sa = smem + buf * HSTAGE + wave * 8 * HBK;   // wave w fills rows [pass * 64 + 8 w, +8)
         float *sb = sa + HBM * HBK;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr)sa, 16, (int)avoff, kglob * 4, 0, 0);
 #pragma unroll
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(HNT, 2) void conv_head_decode_f32(const ConvArgs p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
 
-    fetch();
+    fetch(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -74,24 +74,24 @@ __global__ __launch_bounds__(HNT, 2) void conv_head_decode_f32(const ConvArgs p)
 #pragma unroll
     for (int q = 0; q < 4; ++q) foff[q] = (((2 * q + fh) ^ ((fr >> 1) & 7)) * 4);
 
+    // double-buffered K loop (the conv_f32_mfma LDS-DMA two-stage form): K tile kt+1 lands under the MFMAs of K tile kt
     for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) fetch(cur ^ 1);
+        const float *st = smem + cur * HSTAGE;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 fa = *reinterpret_cast<const f32x4 *>(smem + a_frag + foff[q]);
+            const f32x4 fa = *reinterpret_cast<const f32x4 *>(st + a_frag + foff[q]);
             f32x4 fb[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(smem + b_frag + j * 32 * HBK + foff[q]);
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(st + b_frag + j * 32 * HBK + foff[q]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[j][t], acc[j], 0, 0, 0);
         }
-        __syncthreads();   // every wave is done reading the operand tiles
-        if (kt + 1 < KT) {
-            fetch();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // K tile kt+1 has landed for every wave; every wave is done reading stage cur (and, at the end, both stages)
     }
 
     // ---- the tile (+ bias; the BN scale of a BN head would be folded into the weights) into LDS: C[pixel][channel] -----------

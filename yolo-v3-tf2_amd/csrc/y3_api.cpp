@@ -256,7 +256,7 @@ int choose_tile_x3(const ConvSlot &c, long long M)
 // M = rows of this call (per lane); M_plan = rows of the planned batch.  The MFMA SHAPE (16x16x32 vs 32x32x16: two K groupings,
 // results differ in the last bits) is decided from plan-time quantities only, so that an image's result does not depend on the
 // batch or lane it runs in (y3_net_set_lanes: "results are unchanged"); the tile SIZE within one shape follows the call.
-int choose_tile_bf16(const ConvSlot &c, long long M, long long M_plan)
+int choose_tile_bf16(const ConvSlot &c, long long M, long long M_plan, bool bf16_out)
 {
     auto blocks = [&](int t) {
         y3::TileInfo s = y3::conv_bf16_tile_info(t);
@@ -269,6 +269,9 @@ int choose_tile_bf16(const ConvSlot &c, long long M, long long M_plan)
         if (blocks(24) >= 256) return 24;
         return blocks(27) >= 512 ? 27 : 29;
     }
+    // early 3x3 / stride-1 convs with Cin = 32 / 64 (K = 288 / 576): weights resident in LDS, input patch by LDS-DMA (tile id 32,
+    // conv_res_bf16.hip) -- from the conv's shape alone, so batch- and lane-independent
+    if (bf16_out && c.d.size == 3 && c.d.stride == 1 && c.d.src1 < 0 && (c.d.cin == 32 || c.d.cin == 64) && c.d.cout % 64 == 0) return 32;
     std::vector<int> cand;
     if (c.d.cin % 64)
         cand = {5, 6};                       // BK = 32 (Cin = 32 layers, Cout = 64)
@@ -622,6 +625,8 @@ y3_status y3_net_set_tile_bf16(y3_net *net, int slot, int tile)
         y3::TileInfo s = y3::conv_bf16_tile_info(tile);
         if (c.first_layer || c.cout_pad % s.bn || c.d.cin % s.stages || (c.d.src1 >= 0 && c.d.c0 % s.stages))
             return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile does not fit this conv");
+        if (tile == 32 && !(c.d.size == 3 && c.d.stride == 1 && c.d.src1 < 0 && (c.d.cin == 32 || c.d.cin == 64) && c.d.cout % 64 == 0))
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile 32 (weight-resident) needs a 3x3 / stride-1 conv with 32 or 64 input channels and Cout %% 64 == 0");
     }
     c.tile_bf16 = tile;
     return Y3_OK;
@@ -1028,7 +1033,7 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * 2);
                 const bool out_f32 = is_out(d.dst);
                 if (d.residual >= 0 && out_f32) return fail(Y3_ERR_INVALID, "conv %d: residual on a head output is not supported in bf16 mode", o.index);
-                int tile = c.tile_bf16 >= 0 ? c.tile_bf16 : choose_tile_bf16(c, a.M, (long long)net->max_batch * a.Ho * a.Wo);
+                int tile = c.tile_bf16 >= 0 ? c.tile_bf16 : choose_tile_bf16(c, a.M, (long long)net->max_batch * a.Ho * a.Wo, !out_f32);
                 if (head >= 0 && y3::conv_bf16_tile_info(tile).bn != 256) {   // a box's logits must meet in one workgroup: all 256 channels in the tile
                     const bool m16 = tile >= 24 && tile <= 29;                // keep the MFMA shape of the plan's tile: same K grouping, same bits
                     const bool big = (a.M + 255) / 256 >= 256;                // 256x256 once it fills the chip, else 128x256 (16 waves both)
