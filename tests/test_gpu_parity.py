@@ -93,7 +93,7 @@ def test_conv_layers_match_oracle(rt, case):
 
 def _real_tiles():
     from yolo_v3_tf2_amd._lib import TILES, RETIRED_TILES
-    return [t for t in range(len(TILES)) if t not in RETIRED_TILES]
+    return [t for t in range(len(TILES)) if t not in RETIRED_TILES and t != 33]   # 33: the weight-resident kernel (Cin = 32 only), tested on its own
 
 
 @pytest.mark.parametrize("tile", _real_tiles())
@@ -118,6 +118,44 @@ def test_conv_every_tile_shape(rt, tile):
     for r, g in zip(ref, got):
         g = g.cpu().numpy().reshape(r.shape)
         assert np.abs(g - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
+
+
+@pytest.mark.parametrize("cout,S,B", [(64, 48, 3), (128, 41, 2), (64, 208, 1)])
+def test_f32_weight_resident_conv_bit_identical_to_generic_tiles(rt, cout, S, B):
+    """fp32 tile id 33 (csrc/conv_res_f32.hip): the 3x3 / stride-1 / 32-input-channel conv with its weights resident in registers and
+    its input patch (8 x 16-pixel tiles) fetched by LDS-DMA.  Same k order and lane grouping as conv_f32_mfma, so: BIT-IDENTICAL to
+    the generic 64x64 tile, with and without a shortcut, leaky and linear, on sizes that are not multiples of the tile (41: ragged
+    last row and column of tiles), over several images, and at the network's own 208 x 208; against the oracle within the layer bar."""
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from oracle import oracle as O
+    chain = [dict(filters=cout, size=3), dict(filters=32, size=1), dict(filters=cout, size=3, shortcut=-3),
+             dict(filters=32, size=1, act="linear"), dict(filters=cout, size=3, bn=False, act="linear"), dict(filters=32, size=1)]
+    heads = [dict(filters=64, size=3), dict(filters=128, size=3), dict(filters=64, size=3, bn=False, act="linear")]
+    p = mini_program(32, chain, heads)
+    w = synthetic_weights(p, seed=61)
+    x = np.random.default_rng(61).standard_normal((B, S, S, 32)).astype(np.float32)
+    ref = O.forward(p, w, x)
+    outs = {}
+    for name, tile in (("resident", 33), ("generic", 11)):
+        net = rt.Net(p)
+        net.load_weights(w)
+        forced = 0
+        for slot, o in enumerate(net.conv_ops):
+            if o.size == 3:
+                net.set_tile(slot, tile)
+                forced += 1
+        assert forced == 6
+        net.plan(B, S)
+        outs[name] = [g.clone() for g in net.forward(_cuda(x))]
+        again = net.forward(_cuda(x))
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(outs[name], again))
+    for a, b, r in zip(outs["resident"], outs["generic"], ref):
+        assert torch.equal(a, b)
+        assert np.abs(a.cpu().numpy().reshape(r.shape) - r).max() <= 2e-5 * max(1.0, float(np.abs(r).max()))
+    with pytest.raises(rt.Y3Error):
+        net.set_tile(1, 33)     # the 1x1 conv: tile 33 is for 3x3 / stride-1 / Cin = 32 convs only
 
 
 def test_xcd_blocked_tile_order_is_bit_identical(rt):

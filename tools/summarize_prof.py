@@ -34,7 +34,10 @@ def short(name):
     m = re.search(r"conv_first_f32x3<\d+, (\d)>", name)
     if m:
         return f"conv_first_f32x{m.group(1)}"
-    for k in ("conv_stem_f32", "conv_stem_bf16", "conv_first_f32x3", "conv_first_f32", "conv_first_bf16", "decode_kernel", "nms_kernel", "pack_kernel", "class_scores"):
+    m = re.search(r"conv3x3_res_bf16<(\d+)>", name)
+    if m:
+        return f"conv_res3x3_bf16<cin{m.group(1)}>"
+    for k in ("conv_head_decode_f32", "conv_stem_f32", "conv_stem_bf16", "conv_first_f32x3", "conv_first_f32", "conv_first_bf16", "decode_kernel", "nms_kernel", "pack_kernel", "class_scores"):
         if k in name:
             return k
     return name[:60]

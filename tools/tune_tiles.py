@@ -59,6 +59,8 @@ def main():
             legal = t < 0 or (o.cin != 3 and cp % bn == 0 and not (not bf and t in (20, 21, 22, 25) and o.src1 >= 0))
             if bf and t >= 0:
                 legal = legal and o.cin % TL[t][3] == 0 and (o.src1 < 0 or o.c0 % TL[t][3] == 0)
+            if a.dtype == "f32" and t == 33:    # the weight-resident kernel: 3x3 / stride 1, 32 input channels
+                legal = legal and o.size == 3 and o.stride == 1 and o.src1 < 0 and o.cin == 32 and o.cout % 64 == 0
             if a.dtype == "bf16" and t == 32:   # the weight-resident kernel: 3x3 / stride 1, 32 or 64 input channels, bf16 output
                 legal = legal and o.size == 3 and o.stride == 1 and o.src1 < 0 and o.cin in (32, 64) and o.cout % 64 == 0 and o.dst not in p.outputs
             ok.append(legal)

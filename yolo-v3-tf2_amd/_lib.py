@@ -29,7 +29,8 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
          (128, 128, 4, 1), (128, 128, 4, 1),                # 23/24: 128x128 within 3 / 4 waves per SIMD of registers
          (0, 0, 0, 0),                                      # 25: retired id
          (64, 128, 4, 2), (64, 64, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (256, 32, 4, 2),  # 26..30: LDS-DMA operand loads
-         (64, 128, 4, 1), (64, 64, 4, 1)]                   # 31, 32: LDS-DMA, single LDS stage
+         (64, 128, 4, 1), (64, 64, 4, 1),                   # 31, 32: LDS-DMA, single LDS stage
+         (128, 64, 8, 2)]                                   # 33: weight-resident 3x3 / stride 1 / Cin 32 (csrc/conv_res_f32.hip)
 RETIRED_TILES = tuple(i for i, t in enumerate(TILES) if t[0] == 0)   # ids y3_tile_built answers 0 for
 # three-plane (fp32-accurate on bf16 MFMA) kernel tiles: (BM, BN, waves, BK)
 TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), (256, 64, 4, 32),
@@ -54,7 +55,7 @@ TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4
               (128, 128, 4, 64), (128, 64, 4, 64), (64, 128, 4, 64),       # 27..29: tiles 8, 10, 12 on 16x16x32 MFMAs
               (128, 64, 4, 32), (64, 64, 4, 32),                          # 30, 31: LDS-DMA, BK 32, 64 output channels
               (128, 64, 8, 32)]                                           # 32: weight-resident 3x3 / stride 1, Cin 32 / 64 (csrc/conv_res_bf16.hip)
-TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
+TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 else "") + ("res" if i == 33 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
 
 
 class Y3Error(RuntimeError):

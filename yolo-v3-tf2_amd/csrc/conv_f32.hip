@@ -470,6 +470,7 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {0, 0, 0, 0},                                        // 25: retired id
     {64, 128, 4, 2}, {64, 64, 4, 2}, {128, 128, 4, 2}, {128, 64, 4, 2}, {256, 32, 4, 2},  // 26..30: LDS-DMA loads
     {64, 128, 4, 1}, {64, 64, 4, 1},                     // 31, 32: LDS-DMA, single stage
+    {128, 64, 8, 2},                                     // 33: weight-resident 3x3 / stride 1 / Cin = 32 (conv_res_f32.hip): 8 x 16 pixels x 64 channels per workgroup tile
 };
 
 #ifdef Y3_PHASE_STAMPS
@@ -520,6 +521,7 @@ static hipError_t launch_t(const ConvArgs &a, int stages, hipStream_t s)
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
 {
     if (!conv_tile_built(tile)) return hipErrorInvalidValue;
+    if (tile == 33) return conv_res_f32_fits(a) ? launch_conv_res_f32(a, s) : hipErrorInvalidValue;
     const int stages = kTiles[tile].stages;
     switch (tile) {
         case 0: case 6: return launch_t<2, 2, 2, 2>(a, stages, s);    // 128x128, 4 waves

@@ -330,6 +330,9 @@ int choose_xcd_gn(const ConvSlot &c, const y3::ConvArgs &a, const y3::TileInfo &
 
 int choose_tile(const ConvSlot &c, long long M)
 {
+    // the first residual block's 3x3 (32 -> 64 @208): weights resident in registers, input patch by LDS-DMA (tile id 33, conv_res_f32.hip).
+    // From the conv's shape alone (never the rows of the call); bit-identical to the generic tiles anyway.
+    if (c.d.size == 3 && c.d.stride == 1 && c.d.src1 < 0 && c.d.cin == 32 && c.d.cout % 64 == 0 && c.cout_pad == c.d.cout) return 33;
     // measured on MI355X (tools/tune_tiles.py): many co-resident waves beat big wave tiles for the 64-cycle
     // fp32 MFMA; prefer the largest block tile that still yields >= 2 workgroups per CU
     std::vector<int> cand;
@@ -609,6 +612,8 @@ y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
             return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile id %d is retired (the timing ablations of rounds 1-2; y3_tile_built)", tile);
         y3::TileInfo s = y3::conv_tile_info(tile);
         if (c.first_layer || c.cout_pad % s.bn) return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile does not divide Cout");
+        if (tile == 33 && !(c.d.size == 3 && c.d.stride == 1 && c.d.src1 < 0 && c.d.cin == 32 && c.d.cout % 64 == 0))
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile: tile 33 (weight-resident) needs a 3x3 / stride-1 conv with 32 input channels and Cout %% 64 == 0");
     }
     c.tile = tile;
     return Y3_OK;

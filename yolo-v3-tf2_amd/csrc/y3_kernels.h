@@ -55,12 +55,15 @@ inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes)
 }
 
 // tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
-static constexpr int TILE_COUNT = 33;  // 20..22, 25: retired ids (the timing-only probes of rounds 1-2)
+static constexpr int TILE_COUNT = 34;  // 20..22, 25: retired ids (the timing-only probes of rounds 1-2); 33: the weight-resident 3x3 kernel (conv_res_f32.hip)
 struct TileInfo { int bm, bn, waves, stages; };
 TileInfo conv_tile_info(int tile);
 bool conv_tile_built(int tile);        // false: retired id
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s);
+// weight-resident 3x3 / stride-1 / Cin = 32 conv (conv_res_f32.hip): tile id 33
+bool conv_res_f32_fits(const ConvArgs &a);
+hipError_t launch_conv_res_f32(const ConvArgs &a, hipStream_t s);
 // 1x1 head conv (Cout = 3 * (5 + nc) <= 256) + bias with yolo_decode + arg-max / score fused in (conv_head.hip)
 bool conv_head_decode_f32_fits(const ConvArgs &a);
 hipError_t launch_conv_head_decode_f32(const ConvArgs &a, hipStream_t s);
