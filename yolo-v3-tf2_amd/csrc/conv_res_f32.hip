@@ -45,6 +45,13 @@ __global__ __launch_bounds__(FNT, 2) void conv3x3_res_f32(const ConvArgs p, int 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 31, fh = lane >> 5;
+    // measurement launches only (y3_net_measure_sclk*, same protocol as conv_f32_mfma): thread 0 of the middle workgroup stamps
+    // {s_memtime, s_memrealtime} at its entry and after its last tile, workgroup 0 the kernel's begin.  Null in product launches.
+    if (p.clk_stamps != nullptr && blockIdx.x == (gridDim.x >> 1) && tid == 0) {
+        p.clk_stamps[0] = __builtin_amdgcn_s_memtime();
+        p.clk_stamps[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (p.clk_stamps != nullptr && blockIdx.x == 0 && tid == 0) p.clk_stamps[4] = __builtin_amdgcn_s_memrealtime();
 
     const int slice = (int)blockIdx.x % slices;
     const int sstep = (int)gridDim.x / slices;
@@ -190,6 +197,10 @@ __global__ __launch_bounds__(FNT, 2) void conv3x3_res_f32(const ConvArgs p, int 
                 ooff[it] = ooffn[it];
             }
         }
+    }
+    if (p.clk_stamps != nullptr && blockIdx.x == (gridDim.x >> 1) && tid == 0) {
+        p.clk_stamps[2] = __builtin_amdgcn_s_memtime();
+        p.clk_stamps[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 }  // namespace
