@@ -8,7 +8,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-sclk $*"   # eager launches only: with --graph bench.py times the conv stack in extra forwards that no NMS launch counts
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-sclk --parity-images 0 $*"   # no parity gate: the bf16 gate runs one extra forward that no NMS launch counts   # eager launches only: with --graph bench.py times the conv stack in extra forwards that no NMS launch counts
 echo "== kernel trace / stats"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats -o run --output-format csv -- $BENCH > $out/stats.log 2>&1 || { tail -5 $out/stats.log; exit 1; }
 echo "== pmc pass 1 (SQ/GRBM)"

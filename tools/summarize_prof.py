@@ -37,6 +37,8 @@ def short(name):
     m = re.search(r"conv3x3_res_bf16<(\d+)>", name)
     if m:
         return f"conv_res3x3_bf16<cin{m.group(1)}>"
+    if "conv3x3_res_f32" in name:
+        return "conv_res3x3_f32"
     for k in ("conv_head_decode_f32", "conv_stem_f32", "conv_stem_bf16", "conv_first_f32x3", "conv_first_f32", "conv_first_bf16", "decode_kernel", "nms_kernel", "pack_kernel", "class_scores"):
         if k in name:
             return k

@@ -168,6 +168,12 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
     auto fetch_dma = [&](int buf) {
         unsigned char *sa = smem + buf * STAGE_B + wave * DROWS * ROWB;   // wave w fills rows [pass*RP + DROWS*w, +DROWS)
         unsigned char *sb = sa + BM * ROWB;
+#ifdef Y3_AB_PROBE_A1
+        // timing-only A/B build (WRONG RESULTS, never shipped: tools/ab_libs.py): activations fetched for the first tap only -- the
+        // upper bound of what an LDS-resident halo patch for the 3x3 convs could return (8 of 9 activation fetches gone, no patch cost)
+        if (tap != 0) {
+        } else
+#endif
         if (CONCAT && c0 >= p.C0) {
 #pragma unroll
             for (int i = 0; i < AP; ++i)
