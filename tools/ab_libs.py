@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of two builds of liby3hip.so on ONE box: alternating child processes (Y3_LIB_PATH), each timing the conv stack of
 the headline workload.  Boxes differ by +-2.5 %, processes on one box by < 0.5 %.
-   python tools/ab_libs.py yolo-v3-tf2_amd/lib/liby3hip.so yolo-v3-tf2_amd/lib/liby3hip_var.so [--dtype f32] [--rounds 3]"""
+   python tools/ab_libs.py yolo-v3-tf2_amd/lib/liby3hip.so yolo-v3-tf2_amd/lib/liby3hip_var.so [--dtype f32] [--rounds 3]
+A contender may also be LIB.so@TABLE.json: that build with Y3_TUNING_FILE=TABLE.json (a tile table for the SAME dtype / batch / size)."""
 import argparse
 import os
 import subprocess
@@ -44,7 +45,10 @@ def main():
     res = {lib: [] for lib in a.libs}
     for r in range(a.rounds):
         for lib in a.libs:
-            env = dict(os.environ, Y3_LIB_PATH=os.path.abspath(lib))
+            so, _, table = lib.partition("@")
+            env = dict(os.environ, Y3_LIB_PATH=os.path.abspath(so))
+            if table:
+                env["Y3_TUNING_FILE"] = os.path.abspath(table)
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
             line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
             if not line:
@@ -52,9 +56,9 @@ def main():
                 sys.exit(1)
             ms, tf = line[0].split()[1:]
             res[lib].append(float(ms))
-            print(f"round {r} {os.path.basename(lib):28s} conv stack {ms} ms  {tf} TF/s", flush=True)
+            print(f"round {r} {lib.replace(os.path.dirname(lib.partition(chr(64))[0]) + os.sep, str()):28s} conv stack {ms} ms  {tf} TF/s", flush=True)
     for lib, v in res.items():
-        print(f"{os.path.basename(lib):28s} min {min(v):.3f} ms  mean {sum(v) / len(v):.3f} ms")
+        print(f"{lib.replace(os.path.dirname(lib.partition(chr(64))[0]) + os.sep, str()):28s} min {min(v):.3f} ms  mean {sum(v) / len(v):.3f} ms")
 
 
 if __name__ == "__main__":

@@ -1,15 +1,11 @@
 #!/bin/bash
-# visit 4q: whole GPU suite on HEAD, then the round-end measurements (tools/gpu_final.sh r03)
+# visit 4q: tap-row reuse (bf16 tiles 33..35, conv_bf16_rs.hip): parity first, then the isolated per-layer sweep against the tiles of
+# the same shapes (24, 27, 29) at the per-lane batch (64) and the whole batch (128)
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/4q_tests.log 2>&1 || { tail -30 gpurun_out/4q_tests.log; exit 1; }
-tail -2 gpurun_out/4q_tests.log
-bash tools/gpu_final.sh r03 > gpurun_out/4q_final.log 2>&1 || { tail -30 gpurun_out/4q_final.log; exit 1; }
-grep "rc=" gpurun_out/4q_final.log
-for f in r03_bench_f32_b64_s416 r03_bench_f32_b64_s608 r03_bench_bf16_b128_s416 r03_bench_f32_rccl1 r03_bench_f32_rccl1_graph; do
-  python3 -c "
-import json,sys
-d=json.loads(open('gpurun_out/$f.json').read().strip().splitlines()[-1])
-print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('sclk_mhz'), d.get('parity',{}).get('end_to_end_selection_equal'))"
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tap_row_reuse or weight_resident" > gpurun_out/r4q_tests.txt 2>&1 || { tail -30 gpurun_out/r4q_tests.txt; exit 1; }
+tail -3 gpurun_out/r4q_tests.txt
+for b in 64 128; do
+  timeout -k 10 400 python tools/tune_tiles.py --dtype bf16 --batch $b --tiles 24,27,29,33,34,35 --reps 3 > gpurun_out/r4q_sweep_b$b.txt 2>&1 || { tail -20 gpurun_out/r4q_sweep_b$b.txt; exit 1; }
+  echo "== batch $b"; grep -v amdgpu gpurun_out/r4q_sweep_b$b.txt | grep -E "k3s1_c(128|256|512)|conv  shape|sum" | awk '{c[$2]++; if (c[$2] <= 1 || $1 == "conv") print}'
 done
-tail -4 gpurun_out/r03_config2_backbone.txt

@@ -1,14 +1,17 @@
 #!/bin/bash
-# visit 4t: steady-state coordinate descent over the fp32 table with TWO lanes (op-major enqueue), then bench lanes 1 vs 2 with the result
+# visit 4t: tap-row reuse with one address base per thread (fewer registers in the 128-register 16-wave tile): parity, then in the
+# running pipeline against the shipped table; timing-only builds without the halo pass / with the halo pass masked to its 2 rows
 set -o pipefail
 mkdir -p gpurun_out
-cp yolo-v3-tf2_amd/tuning/f32_b64_s416.json gpurun_out/4t_f32_table_before.json
-timeout -k 10 900 python tools/tune_steady.py --dtype f32 --batch 64 --lanes 2 --steps 15 --write f32_b64_s416.json > gpurun_out/4t_tune_steady_f32_lanes2.txt 2>&1 || { tail -20 gpurun_out/4t_tune_steady_f32_lanes2.txt; exit 1; }
-grep -v "keeps tile" gpurun_out/4t_tune_steady_f32_lanes2.txt | grep -v amdgpu
-cp yolo-v3-tf2_amd/tuning/f32_b64_s416.json gpurun_out/4t_f32_table_after.json
-for rep in 1 2; do
-  for l in 1 2; do
-    timeout -k 10 300 python bench.py --lanes $l --steps 30 --warmup 10 --no-cpu-baseline --no-alt --no-sclk > gpurun_out/4t_f32.log 2>&1 || { tail -20 gpurun_out/4t_f32.log; exit 1; }
-    echo "tuned-for-2-lanes table, lanes=$l rep=$rep $(tail -n 1 gpurun_out/4t_f32.log | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["roofline"]["frac"])')"
-  done
+L=yolo-v3-tf2_amd/lib
+T=tools/tables/bf16_b128_s416_rs.json
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tap_row_reuse" > gpurun_out/r4t_tests.txt 2>&1 || { tail -30 gpurun_out/r4t_tests.txt; exit 1; }
+tail -1 gpurun_out/r4t_tests.txt
+Y3_LIB_PATH=$PWD/$L/liby3hip_rs_HALO_MASKED.so timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tap_row_reuse" > gpurun_out/r4t_tests_masked.txt 2>&1 || { tail -30 gpurun_out/r4t_tests_masked.txt; exit 1; }
+tail -1 gpurun_out/r4t_tests_masked.txt
+timeout -k 10 800 python tools/ab_libs.py $L/liby3hip.so $L/liby3hip.so@$T $L/liby3hip_rs_NO_EXTRA.so@$T $L/liby3hip_rs_HALO_MASKED.so@$T --dtype bf16 --batch 128 --rounds 3 > gpurun_out/r4t_ab_bf16_rs.txt 2>&1 || { tail -20 gpurun_out/r4t_ab_bf16_rs.txt; exit 1; }
+grep -v amdgpu gpurun_out/r4t_ab_bf16_rs.txt | tail -4
+for v in "" _rs_NO_EXTRA _rs_HALO_MASKED; do
+  Y3_LIB_PATH=$PWD/$L/liby3hip$v.so timeout -k 10 300 python tools/tune_tiles.py --dtype bf16 --batch 64 --tiles 24,33 --reps 3 > gpurun_out/r4t_sweep$v.txt 2>&1 || { tail -20 gpurun_out/r4t_sweep$v.txt; exit 1; }
+  echo "== liby3hip$v"; grep -v amdgpu gpurun_out/r4t_sweep$v.txt | grep -E "k3s1_c(128|256|512)|sum" | awk '{c[$2]++; if (c[$2] <= 1) print}'
 done

@@ -168,12 +168,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
     auto fetch_dma = [&](int buf) {
         unsigned char *sa = smem + buf * STAGE_B + wave * DROWS * ROWB;   // wave w fills rows [pass*RP + DROWS*w, +DROWS)
         unsigned char *sb = sa + BM * ROWB;
-#ifdef Y3_AB_PROBE_A1
-        // timing-only A/B build (WRONG RESULTS, never shipped: tools/ab_libs.py): activations fetched for the first tap only -- the
-        // upper bound of what an LDS-resident halo patch for the 3x3 convs could return (8 of 9 activation fetches gone, no patch cost)
-        if (tap != 0) {
-        } else
-#endif
         if (CONCAT && c0 >= p.C0) {
 #pragma unroll
             for (int i = 0; i < AP; ++i)
@@ -453,6 +447,7 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64}, {128, 128, 4, 64}, {128, 64, 4, 64}, {64, 128, 4, 64},  // 24..29: 16x16x32 MFMAs
     {128, 64, 4, 32}, {64, 64, 4, 32},                            // 30, 31: LDS-DMA with BK = 32 for the Cin = 32 / Cout = 64 layer
     {128, 64, 8, 32},                                             // 32: weight-resident 3x3 / stride 1, Cin = 32 / 64 (conv_res_bf16.hip): 4 x 32 pixels x 64 channels per workgroup tile
+    {256, 256, 16, 64}, {128, 128, 4, 64}, {64, 128, 4, 64},      // 33..35: 3x3 / stride 1 with tap-row reuse (conv_bf16_rs.hip), the shapes of tiles 24, 27, 29
 };
 
 #ifdef Y3_PHASE_STAMPS
@@ -499,6 +494,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
     if (a.dst == nullptr && a.dec.boxes == nullptr) return hipErrorInvalidValue;
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
     if (tile == 32) return (!out_f32 && conv_res_bf16_fits(a)) ? launch_conv_res_bf16(a, s) : hipErrorInvalidValue;
+    if (tile >= 33 && tile <= 35) return (!out_f32 && conv_bf16_rs_fits(a)) ? launch_conv_bf16_rs(a, tile, s) : hipErrorInvalidValue;
     switch (tile) {
         case 0: return launch_tb<2, 2, 2, 2, 64>(a, out_f32, s);
         case 1: return launch_tb<2, 2, 4, 2, 64>(a, out_f32, s);
