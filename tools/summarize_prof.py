@@ -34,6 +34,10 @@ def short(name):
     m = re.search(r"conv_first_f32x3<\d+, (\d)>", name)
     if m:
         return f"conv_first_f32x{m.group(1)}"
+    m = re.search(r"conv_bf16_rs<(\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+    if m:
+        tm, tn, wr, wc = (int(m.group(i)) for i in range(1, 5))
+        return f"conv_bf16_rs<{32*tm*wr}x{32*tn*wc},w{wr*wc}{',16x16x32' if m.group(5) == 'true' else ''}>"
     m = re.search(r"conv3x3_res_bf16<(\d+)>", name)
     if m:
         return f"conv_res3x3_bf16<cin{m.group(1)}>"
