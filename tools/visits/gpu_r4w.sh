@@ -1,15 +1,12 @@
 #!/bin/bash
-# visit 4w: the lanes' stem kernels side by side (each takes 1/lanes of the persistent workgroup slots) vs one after the other (Y3_STEM_SHARE=0)
+# visit 4w: timing-only bound: bf16 generic kernel without the shortcut operand (no loads, no adds; wrong results) -- what hiding the
+# shortcut loads behind the K loop could return at most
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "stem or lane" > gpurun_out/4w_tests.log 2>&1 || { tail -40 gpurun_out/4w_tests.log; exit 1; }
-tail -1 gpurun_out/4w_tests.log
-for rep in 1 2 3; do
-  for sh in 1 0; do
-    export Y3_STEM_SHARE=$sh
-    timeout -k 10 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-alt --no-sclk > gpurun_out/4w.log 2>&1 || { tail -20 gpurun_out/4w.log; exit 1; }
-    echo "f32 share=$sh rep=$rep $(tail -n 1 gpurun_out/4w.log | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["roofline"]["frac"])')"
-    timeout -k 10 300 python bench.py --dtype bf16 --batch 128 --graph --steps 30 --warmup 10 --no-cpu-baseline --no-sclk > gpurun_out/4w.log 2>&1 || { tail -20 gpurun_out/4w.log; exit 1; }
-    echo "bf16 share=$sh rep=$rep $(tail -n 1 gpurun_out/4w.log | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"
-  done
+L=yolo-v3-tf2_amd/lib
+timeout -k 10 700 python tools/ab_libs.py $L/liby3hip.so $L/liby3hip_nores.so --dtype bf16 --batch 128 --rounds 3 > gpurun_out/r4w_ab_bf16_nores.txt 2>&1 || { tail -20 gpurun_out/r4w_ab_bf16_nores.txt; exit 1; }
+grep -v amdgpu gpurun_out/r4w_ab_bf16_nores.txt | tail -3
+for l in liby3hip liby3hip_nores; do
+  Y3_LIB_PATH=$PWD/$L/$l.so timeout -k 10 300 python tools/tune_tiles.py --dtype bf16 --batch 64 --tiles 24 --reps 3 > gpurun_out/r4w_sweep_$l.txt 2>&1 || { tail -20 gpurun_out/r4w_sweep_$l.txt; exit 1; }
+  echo "== $l"; grep -v amdgpu gpurun_out/r4w_sweep_$l.txt | grep -E "k3s1_c(128|256|512)|sum" | awk '{c[$2]++; if (c[$2] <= 1) print}'
 done
