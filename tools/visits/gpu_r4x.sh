@@ -1,7 +1,14 @@
 #!/bin/bash
-# visit 4x: steady-state coordinate descent over the fp32 table of 64 x 608^2 with two lanes; then the bf16 table once more on HEAD
+# visit 4x: bf16 generic kernel with the last K tile peeled and the first block's shortcut rows requested before its MFMAs:
+# parity (bit-identical arithmetic), then alternating processes against the committed library
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1100 python tools/tune_steady.py --dtype f32 --batch 64 --image-size 608 --lanes 2 --steps 8 --write f32_b64_s608.json > gpurun_out/4x_tune_steady_f32_s608.txt 2>&1 || { tail -20 gpurun_out/4x_tune_steady_f32_s608.txt; exit 1; }
-grep -v "keeps tile" gpurun_out/4x_tune_steady_f32_s608.txt | grep -v amdgpu
-cp yolo-v3-tf2_amd/tuning/f32_b64_s608.json gpurun_out/4x_f32_b64_s608.json
+L=yolo-v3-tf2_amd/lib
+Y3_LIB_PATH=$PWD/$L/liby3hip_earlyres.so timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "bf16" > gpurun_out/r4x_tests.txt 2>&1 || { tail -30 gpurun_out/r4x_tests.txt; exit 1; }
+tail -1 gpurun_out/r4x_tests.txt
+timeout -k 10 700 python tools/ab_libs.py $L/liby3hip.so $L/liby3hip_earlyres.so --dtype bf16 --batch 128 --rounds 4 > gpurun_out/r4x_ab_bf16_earlyres.txt 2>&1 || { tail -20 gpurun_out/r4x_ab_bf16_earlyres.txt; exit 1; }
+grep -v amdgpu gpurun_out/r4x_ab_bf16_earlyres.txt | tail -3
+for l in liby3hip liby3hip_earlyres; do
+  Y3_LIB_PATH=$PWD/$L/$l.so timeout -k 10 300 python tools/tune_tiles.py --dtype bf16 --batch 64 --tiles 24 --reps 3 > gpurun_out/r4x_sweep_$l.txt 2>&1 || { tail -20 gpurun_out/r4x_sweep_$l.txt; exit 1; }
+  echo "== $l"; grep -v amdgpu gpurun_out/r4x_sweep_$l.txt | grep -E "k3s1_c(128|256|512)|sum" | awk '{c[$2]++; if (c[$2] <= 1) print}'
+done
