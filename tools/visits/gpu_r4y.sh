@@ -1,10 +1,13 @@
 #!/bin/bash
-# visit 4y: smoke() + the 608 tests + bench at 608 with the re-tuned table
+# visit 4y: the power wall in the running step: the same library, the same launches, on random data and on all-zero weights + images
+# (nothing toggles in the matrix pipes or on the data paths) -- conv stack per step, bf16 (128 images) and fp32 (64 images)
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/4y_smoke.log 2>&1 || { tail -20 gpurun_out/4y_smoke.log; exit 1; }
-tail -1 gpurun_out/4y_smoke.log
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "608" > gpurun_out/4y_tests.log 2>&1 || { tail -40 gpurun_out/4y_tests.log; exit 1; }
-tail -1 gpurun_out/4y_tests.log
-timeout -k 10 300 python bench.py --image-size 608 --steps 10 --warmup 3 --no-alt --no-cpu-baseline > gpurun_out/r03_bench_f32_b64_s608.json 2> gpurun_out/4y.err || { tail -20 gpurun_out/4y.err; exit 1; }
-python3 -c 'import json; d=json.loads(open("gpurun_out/r03_bench_f32_b64_s608.json").read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["parity"]["end_to_end_selection_equal"])'
+L=yolo-v3-tf2_amd/lib
+for dt in bf16:128 f32:64; do
+  d=${dt%%:*}; b=${dt##*:}
+  for data in rand zeros rand zeros; do
+    timeout -k 10 300 python tools/ab_libs.py $L/liby3hip.so --dtype $d --batch $b --rounds 1 --data $data > gpurun_out/r4y_tmp.txt 2>&1 || { tail -20 gpurun_out/r4y_tmp.txt; exit 1; }
+    echo "$d b$b $data: $(grep -v amdgpu gpurun_out/r4y_tmp.txt | grep '^round')" | tee -a gpurun_out/r4y_power_wall.txt
+  done
+done
