@@ -25,7 +25,7 @@ CANDIDATES = {
     "f32": [3, 4, 5, 6, 9, 10, 11, 12, 17, 18, 23, 26, 27, 29, 31, 32],
     "f32x2": [0, 1, 2, 3, 4, 8, 12, 26, 27],
     "f32x3": [0, 1, 2, 3, 4, 5, 8, 12, 26, 27],
-    "bf16": [0, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32],
+    "bf16": [0, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35],
 }
 
 
