@@ -111,6 +111,9 @@ y3_status y3_net_set_conv_weights(y3_net *net, int conv_slot, const float *w, co
 
 /* Tuning/testing knobs (no reference counterpart).
  * y3_net_set_tile: force the block tile of one conv (index into the kernel's tile table; -1 = heuristic).
+ * bf16 tiles 33..35 (3x3 / stride-1 convs with Cin % 128 == 0: one activation tile per kernel row, csrc/conv_bf16_rs.hip) walk K as
+ * (kernel row, channel chunk, kernel column): equal to the other bf16 tiles up to the final rounding to bf16, not bit for bit (as
+ * already between the 32x32x16 and the 16x16x32 tiles); neither the heuristic nor a packaged table selects them.
  * y3_net_keep_activations(1) before y3_net_plan: no buffer reuse, so y3_net_read_tensor can read any
  * intermediate after a forward. */
 y3_status y3_net_set_tile(y3_net *net, int conv_slot, int tile);
