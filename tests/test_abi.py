@@ -102,7 +102,7 @@ def test_tile_built_reports_the_default_tile_set():
     assert not _lib.tile_built(7, 0)
     assert x3 == list(_lib.TILES_X3_BUILT) and x2 == list(_lib.TILES_X2_BUILT)
     assert f32 == [t for t in range(len(_lib.TILES)) if _lib.TILES[t][0] > 0] == list(range(20)) + [23, 24] + list(range(26, len(_lib.TILES)))
-    assert bf16 == [t for t in range(len(_lib.TILES_BF16)) if _lib.TILES_BF16[t][0] > 0] == list(range(20)) + list(range(21, 36))   # 32: weight-resident 3x3; 33..35: tap-row reuse
+    assert bf16 == [t for t in range(len(_lib.TILES_BF16)) if _lib.TILES_BF16[t][0] > 0] == list(range(20)) + list(range(21, 37))   # 32: weight-resident 3x3; 33..35: tap-row reuse; 36: four waves of 128x128
     assert _lib.RETIRED_TILES == (20, 21, 22, 25)
     # every tile a committed tuning table names is in the default set
     import glob

@@ -574,6 +574,55 @@ def test_bf16_tap_row_reuse_3x3_matches_oracle_and_generic_tiles(rt, tile, cin, 
     assert float((a != b).mean()) <= 0.004
 
 
+@pytest.mark.parametrize("cin,S,B", [(128, 14, 5), (64, 20, 2), (256, 10, 7), (128, 26, 1)])
+def test_bf16_four_wave_tile_bit_identical_to_the_16_wave_tile(rt, cin, S, B):
+    """bf16 tile id 36 (csrc/conv_bf16_w4.hip): the 256 x 256 block tile on FOUR waves of 128 x 128 (256 accumulator registers, one wave
+    per SIMD, fragment reads of the next k-step and the LDS-DMA requests of the tile after next issued between the MFMAs).  Same K
+    order and MFMA shape as the 32x32x16 tiles, so every output must equal tile 17's (256 x 256 on 16 waves) bit for bit: 3x3 stride 1
+    and 2, 1x1, with and without a shortcut, BN + leaky and linear + bias, pixel counts that leave a ragged last tile and tiles that
+    cross images; and the oracle's bf16 bars on top."""
+    from tests.helpers import mini_program
+    from yolo_v3_tf2_amd.weights import synthetic_weights
+    from yolo_v3_tf2_amd import _lib
+    from oracle import oracle as O
+    chain = [dict(filters=256, size=3), dict(filters=256, size=1), dict(filters=256, size=3, shortcut=-3),
+             dict(filters=256, size=1, act="linear"), dict(filters=256, size=3, stride=2, bn=False, act="linear")]
+    heads = [dict(filters=64, size=1), dict(filters=32, size=1), dict(filters=64, size=1, bn=False, act="linear")]
+    p = mini_program(cin, chain, heads)
+    w = synthetic_weights(p, seed=54)
+    x = np.random.default_rng(54).standard_normal((B, S, S, cin)).astype(np.float32)
+    ops = p.conv_ops()
+    probe = [o.dst for o in ops if o.cout == 256]
+    assert len(probe) == 5
+    ref, kept = O.forward(p, w, x, bf16=True, keep=set(probe))
+    xin = _cuda(O.round_bf16(x)).to(torch.bfloat16)
+    outs, mids = {}, {}
+    for name, tile in (("w4", 36), ("w16", 17)):
+        net = rt.Net(p)
+        net.load_weights(w)
+        net.keep_activations(True)
+        n_set = 0
+        for slot, o in enumerate(net.conv_ops):
+            if o.cout == 256 and (o.size * o.size * o.cin) % 128 == 0:   # tile 36 wants an even number of 64-wide K tiles
+                net.set_tile_bf16(slot, tile)
+                n_set += 1
+        assert n_set == (4 if cin == 64 else 5)
+        net.plan(B, S, _lib.Y3_DTYPE_BF16)
+        outs[name] = [g.clone() for g in net.forward(xin)]
+        mids[name] = [net.read_tensor(t, B).clone() for t in probe]
+        again = net.forward(xin)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(outs[name], again))
+        for r, g in zip(ref, outs[name]):
+            g = g.cpu().numpy().reshape(r.shape)
+            assert np.abs(g - r).max() <= 4e-3 * max(1.0, float(np.abs(r).max())), (name, float(np.abs(g - r).max()))
+    g0 = mids["w4"][0].float().cpu().numpy()
+    d = np.abs(g0 - kept[probe[0]])
+    assert (d <= _bf16_ulp_elem(g0, kept[probe[0]]) + 1e-5 * float(np.abs(kept[probe[0]]).max())).all()
+    for k, (a, b) in enumerate(zip(mids["w4"] + outs["w4"], mids["w16"] + outs["w16"])):
+        assert torch.equal(a, b), k
+
+
 def test_bf16_intermediate_tensors_within_one_ulp(rt, program, weights):
     """Intermediate bf16 activations (after residual adds / the fused upsample+concat conv) vs the bf16 oracle."""
     from yolo_v3_tf2_amd import _lib

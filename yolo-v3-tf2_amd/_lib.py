@@ -55,7 +55,8 @@ TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4
               (128, 128, 4, 64), (128, 64, 4, 64), (64, 128, 4, 64),       # 27..29: tiles 8, 10, 12 on 16x16x32 MFMAs
               (128, 64, 4, 32), (64, 64, 4, 32),                          # 30, 31: LDS-DMA, BK 32, 64 output channels
               (128, 64, 8, 32),                                           # 32: weight-resident 3x3 / stride 1, Cin 32 / 64 (csrc/conv_res_bf16.hip)
-              (256, 256, 16, 64), (128, 128, 4, 64), (64, 128, 4, 64)]    # 33..35: 3x3 / stride 1, Cin % 128 == 0, tap-row reuse (csrc/conv_bf16_rs.hip)
+              (256, 256, 16, 64), (128, 128, 4, 64), (64, 128, 4, 64),    # 33..35: 3x3 / stride 1, Cin % 128 == 0, tap-row reuse (csrc/conv_bf16_rs.hip)
+              (256, 256, 4, 64)]                                          # 36: 256x256 on four waves of 128x128, software-pipelined (csrc/conv_bf16_w4.hip)
 TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 else "") + ("res" if i == 33 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
 
 

@@ -448,6 +448,7 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {128, 64, 4, 32}, {64, 64, 4, 32},                            // 30, 31: LDS-DMA with BK = 32 for the Cin = 32 / Cout = 64 layer
     {128, 64, 8, 32},                                             // 32: weight-resident 3x3 / stride 1, Cin = 32 / 64 (conv_res_bf16.hip): 4 x 32 pixels x 64 channels per workgroup tile
     {256, 256, 16, 64}, {128, 128, 4, 64}, {64, 128, 4, 64},      // 33..35: 3x3 / stride 1 with tap-row reuse (conv_bf16_rs.hip), the shapes of tiles 24, 27, 29
+    {256, 256, 4, 64},                                             // 36: 256x256 on four waves of 128x128, software-pipelined (conv_bf16_w4.hip)
 };
 
 #ifdef Y3_PHASE_STAMPS
@@ -494,6 +495,7 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
     if (a.dst == nullptr && a.dec.boxes == nullptr) return hipErrorInvalidValue;
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
     if (tile == 32) return (!out_f32 && conv_res_bf16_fits(a)) ? launch_conv_res_bf16(a, s) : hipErrorInvalidValue;
+    if (tile == 36) return (!out_f32 && conv_bf16_w4_fits(a)) ? launch_conv_bf16_w4(a, s) : hipErrorInvalidValue;
     if (tile >= 33 && tile <= 35) return (!out_f32 && conv_bf16_rs_fits(a)) ? launch_conv_bf16_rs(a, tile, s) : hipErrorInvalidValue;
     switch (tile) {
         case 0: return launch_tb<2, 2, 2, 2, 64>(a, out_f32, s);

@@ -632,6 +632,8 @@ y3_status y3_net_set_tile_bf16(y3_net *net, int slot, int tile)
             return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile does not fit this conv");
         if (tile == 32 && !(c.d.size == 3 && c.d.stride == 1 && c.d.src1 < 0 && (c.d.cin == 32 || c.d.cin == 64) && c.d.cout % 64 == 0))
             return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile 32 (weight-resident) needs a 3x3 / stride-1 conv with 32 or 64 input channels and Cout %% 64 == 0");
+        if (tile == 36 && !(c.d.src1 < 0 && c.cout_pad == c.d.cout && (c.d.size * c.d.size * c.d.cin) % 128 == 0))
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile 36 (four waves of 128x128) needs a conv without a concat source, unpadded Cout %% 256 == 0 and an even number of 64-wide K tiles");
         if (tile >= 33 && tile <= 35 && !(c.d.size == 3 && c.d.stride == 1 && c.d.src1 < 0 && c.d.cin % 128 == 0 && c.cout_pad == c.d.cout))
             return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tiles 33..35 (tap-row reuse) need a 3x3 / stride-1 conv with Cin %% 128 == 0 and unpadded Cout");
     }

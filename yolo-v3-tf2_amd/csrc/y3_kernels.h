@@ -101,7 +101,7 @@ hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s);
 hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s);   // conv0 on bf16 MFMA from split (hi + lo) operands (~2^-16 per product), bf16 patch, conv1 on bf16 MFMA
 
 // bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
-static constexpr int BF16_TILE_COUNT = 36;   // 32: the weight-resident 3x3 kernel (conv_res_bf16.hip); 33..35: tap-row reuse (conv_bf16_rs.hip)
+static constexpr int BF16_TILE_COUNT = 37;   // 32: the weight-resident 3x3 kernel (conv_res_bf16.hip); 33..35: tap-row reuse (conv_bf16_rs.hip)
 TileInfo conv_bf16_tile_info(int tile);
 bool conv_bf16_tile_built(int tile);
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);
@@ -111,6 +111,9 @@ hipError_t launch_conv_res_bf16(const ConvArgs &a, hipStream_t s);
 // 3x3 / stride-1 conv with the activation tile fetched once per kernel ROW and reused for its three taps (conv_bf16_rs.hip): Cin % 128 == 0
 bool conv_bf16_rs_fits(const ConvArgs &a);
 hipError_t launch_conv_bf16_rs(const ConvArgs &a, int tile, hipStream_t s);
+// 256 x 256 block tile on four waves of 128 x 128 (one per SIMD), software-pipelined fragment reads (conv_bf16_w4.hip): bf16 tile id 36
+bool conv_bf16_w4_fits(const ConvArgs &a);
+hipError_t launch_conv_bf16_w4(const ConvArgs &a, hipStream_t s);
 hipError_t launch_conv_first_bf16(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void *x, float *y, size_t n, hipStream_t s);
 
