@@ -48,8 +48,13 @@ def build(force=False, verbose=False, defines=(), out=None, only=None):
 
 
 def _build_variant(defines, out, only, verbose):
-    build()                                   # default objects first
+    # The default objects of the OTHER sources are linked as they are; nothing of the default build is recompiled here.  (Until visit 4af this
+    # called build() first -- with a source edited in place for the variant, that rebuilt the DEFAULT library from the edited source as well, and
+    # an A/B of "default vs variant" compared a build with itself: profiles/r04_ab_bf16_shortcut.txt, r04_ab_f32_nofetch1x1.txt were re-measured.)
     objdir = os.path.join(HERE, "build")
+    missing = [s for s in SOURCES if s not in only and not os.path.exists(os.path.join(objdir, s + ".o"))]
+    if missing:
+        raise SystemExit(f"build the default library first (python build.py): no object for {missing}")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tag = "_".join(d.replace("=", "") for d in defines) or "var"
     objs = []
