@@ -392,6 +392,18 @@ def main():
     # parity gate: nothing is timed or reported unless the path's results on this very batch
     # match the oracle; fp32-accurate modes only (bf16 is measured against its own bar in tests/)
     parity = None
+    fused_equal = None
+    if rank == 0 and args.parity_images > 0:
+        # the route the loop times (y3_net_forward_decode: the head convs decode their own tiles) against the composed route
+        # (forward into grids + y3_yolo_decode_scores) on this very plan and batch: bit-identical by contract, checked here at the
+        # bench's geometry for both dtypes (the bf16 gate below compares head logits, which the timed route never writes)
+        fb, fc, fs = net.forward_decode(images, anchors)
+        cb, cc, cs = runtime.yolo_decode_scores(net.forward(images, out=grids), anchors, nc)
+        torch.cuda.synchronize()
+        fused_equal = bool(torch.equal(fb, cb) and torch.equal(fc, cc) and torch.equal(fs, cs))
+        if not fused_equal:
+            raise SystemExit("PARITY GATE FAILED: y3_net_forward_decode differs from y3_net_forward + y3_yolo_decode_scores on the bench's plan -- no number reported")
+        del fb, fc, fs, cb, cc, cs
     if rank == 0 and args.parity_images > 0 and args.dtype != "bf16":
         torch.cuda.synchronize()
         parity = parity_gate(program, weights, anchors, images_host, last["tuple"], min(args.parity_images, B), M, 0.5, 0.1)
@@ -543,7 +555,10 @@ def main():
             "config": {"workload": f"full YOLOv3 detect, {B} images/GPU, {S}x{S}, 80 classes, { {'f32': 'fp32', 'f32x2': 'fp16 (two-plane fp32)', 'f32x3': 'bf16 (three-plane fp32)'}.get(args.dtype, 'bf16') } MFMA conv, "
                                    f"decode + class-agnostic NMS (max 100, iou 0.5, score 0.1), packed detections"
                                    + (", RCCL all-gather" if use_dist else ""),
-                       "collective": collective, "rccl_ranks": world if use_dist else 0,
+                       # rccl_ranks: ranks that really exchanged over RCCL in this run (0 for one rank without a collective AND for
+                       # the gloo rehearsal, which never touches RCCL; "rehearsal" says which of the two it was)
+                       "collective": collective, "rccl_ranks": world if (use_dist and not rehearse) else 0,
+                       "rehearsal": bool(use_dist and rehearse),
                        "rank_order_checked": bool(use_dist), "hip_graph": graph is not None,
                        "lanes": headline_lanes,   # concurrent sub-batches per forward (tuning table / --lanes)
                        "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}",
@@ -564,6 +579,7 @@ def main():
         }
         line["parity_checked"] = parity["images"] if parity else 0
         if parity:
+            parity["timed_route_equals_composed_route"] = fused_equal
             line["parity"] = parity
         for tag, alt in alts.items():
             line["alt_" + tag] = alt

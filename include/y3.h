@@ -9,7 +9,9 @@
  *
  * Conventions
  *   - plain C types only; every function returns y3_status (0 = OK, <0 = error) and never
- *     throws or aborts.  y3_last_error() returns a thread-local message for the last failure.
+ *     throws or aborts: each entry point that can reach a host allocation is a function-try-block, so a failed allocation
+ *     comes back as Y3_ERR_OOM (any other C++ exception as Y3_ERR_INTERNAL) with a message, not as a terminated host process.
+ *     y3_last_error() returns a thread-local message for the last failure (a fixed buffer: reporting allocates nothing).
  *   - "dev" pointers are device (HBM) addresses owned by the caller (e.g. torch `data_ptr()`);
  *     "host" pointers are ordinary host memory, copied during the call.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
@@ -36,7 +38,8 @@ enum {
     Y3_ERR_OOM = -3,       /* device allocation failed */
     Y3_ERR_STATE = -4,     /* call order (weights missing, plan missing, ...) */
     Y3_ERR_NODEVICE = -5,  /* no usable GPU */
-    Y3_ERR_COMM = -6       /* RCCL error (or librccl not loadable) */
+    Y3_ERR_COMM = -6,      /* RCCL error (or librccl not loadable) */
+    Y3_ERR_INTERNAL = -7   /* a C++ exception other than std::bad_alloc (reported as Y3_ERR_OOM) was stopped at the boundary */
 };
 
 /* activation storage / MFMA input type of the conv stack */
@@ -47,9 +50,10 @@ const char *y3_last_error(void);
 /* number of visible HIP devices (0 when none); never fails */
 int y3_device_count(void);
 /* 1 when tile id `tile` of the conv kernel family of `dtype` (Y3_DTYPE_*) exists in this library, else 0.  Tile ids are stable
- * (tuning tables refer to them); the ids of tiles that were measured and lost in rounds 1-3 (timing-only ablations, the
- * stream-K schedule, residual prefetch, the pipelined bf16 tile; DESIGN.md section 4, records under profiles/) are retired
- * and answer 0. */
+ * (tuning tables refer to them); the ids of tiles that were measured and lost in rounds 1-4 (timing-only ablations, the
+ * stream-K schedule, residual prefetch, the pipelined bf16 tile, bf16 tap-row reuse and the four-wave 256x256 bf16 tile;
+ * DESIGN.md section 4, records under profiles/) are retired and answer 0.  Every id that answers 1 is named by a packaged
+ * tuning table or chosen by the library's heuristic for some conv (tests/test_abi.py). */
 int y3_tile_built(int dtype, int tile);
 
 /* ------------------------------------------------------------------------------------------
@@ -111,9 +115,8 @@ y3_status y3_net_set_conv_weights(y3_net *net, int conv_slot, const float *w, co
 
 /* Tuning/testing knobs (no reference counterpart).
  * y3_net_set_tile: force the block tile of one conv (index into the kernel's tile table; -1 = heuristic).
- * bf16 tiles 33..35 (3x3 / stride-1 convs with Cin % 128 == 0: one activation tile per kernel row, csrc/conv_bf16_rs.hip) walk K as
- * (kernel row, channel chunk, kernel column): equal to the other bf16 tiles up to the final rounding to bf16, not bit for bit (as
- * already between the 32x32x16 and the 16x16x32 tiles); neither the heuristic nor a packaged table selects them.
+ * A tile that cannot serve the conv (shape, or a bf16-only tile on a conv that writes an fp32 net output) is refused here with
+ * Y3_ERR_INVALID and a message, not by the forward.
  * y3_net_keep_activations(1) before y3_net_plan: no buffer reuse, so y3_net_read_tensor can read any
  * intermediate after a forward. */
 y3_status y3_net_set_tile(y3_net *net, int conv_slot, int tile);

@@ -32,8 +32,10 @@ def test_bench_two_ranks_rehearsal(extra, scaling, global_batch):
     assert len(lines) == 1, r.stdout[-2000:]          # exactly one JSON line, from rank 0
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["global_batch"] == global_batch
-    assert d["config"]["rank_order_checked"] is True and d["config"]["rccl_ranks"] == 2
+    # the rehearsal exchanges over gloo: no rank touched RCCL, and the line says so in the one field a reader checks for it
+    assert d["config"]["rank_order_checked"] is True and d["config"]["rccl_ranks"] == 0 and d["config"]["rehearsal"] is True
     assert d["config"]["collective"].startswith("REHEARSAL")
+    assert d["parity"]["timed_route_equals_composed_route"] is True
     assert d["parity_checked"] == 2 and d["parity"]["nms_index_selection"].startswith("bit-exact")
     assert d["value"] > 0 and abs(d["value"] - global_batch * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) <= 0.02 * d["value"]
 
@@ -74,7 +76,7 @@ def test_bench_launcherless_two_ranks_rehearsal():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["rank_order_checked"] is True
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 0 and d["config"]["rehearsal"] is True and d["config"]["rank_order_checked"] is True
     assert d["config"]["collective"].startswith("REHEARSAL") and d["parity_checked"] == 2
 
 

@@ -2,7 +2,8 @@
 """A/B of two builds of liby3hip.so on ONE box: alternating child processes (Y3_LIB_PATH), each timing the conv stack of
 the headline workload.  Boxes differ by +-2.5 %, processes on one box by < 0.5 %.
    python tools/ab_libs.py yolo-v3-tf2_amd/lib/liby3hip.so yolo-v3-tf2_amd/lib/liby3hip_var.so [--dtype f32] [--rounds 3]
-A contender may also be LIB.so@TABLE.json: that build with Y3_TUNING_FILE=TABLE.json (a tile table for the SAME dtype / batch / size)."""
+A contender may also be LIB.so@TABLE.json: that build with Y3_TUNING_FILE=TABLE.json (a tile table for the SAME dtype / batch / size),
+and carry environment settings for its child process after a percent sign: LIB.so%Y3_LANE_STAGGER=1,OTHER=2 (tool knobs of the library)."""
 import argparse
 import os
 import subprocess
@@ -50,8 +51,11 @@ def main():
     res = {lib: [] for lib in a.libs}
     for r in range(a.rounds):
         for lib in a.libs:
-            so, _, table = lib.partition("@")
+            spec, _, envs = lib.partition("%")
+            so, _, table = spec.partition("@")
             env = dict(os.environ, Y3_LIB_PATH=os.path.abspath(so))
+            for kv in [v for v in envs.split(",") if v]:
+                env[kv.partition("=")[0]] = kv.partition("=")[2]
             if table:
                 env["Y3_TUNING_FILE"] = os.path.abspath(table)
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)

@@ -22,10 +22,10 @@ from yolo_v3_tf2_amd.graph import load_program  # noqa: E402
 from yolo_v3_tf2_amd.weights import synthetic_weights  # noqa: E402
 
 CANDIDATES = {
-    "f32": [3, 4, 5, 6, 9, 10, 11, 12, 17, 18, 23, 26, 27, 29, 31, 32],
+    "f32": [3, 4, 5, 6, 9, 10, 11, 12, 17, 18, 23, 26, 27, 29, 31, 32, 34],
     "f32x2": [0, 1, 2, 3, 4, 8, 12, 26, 27],
     "f32x3": [0, 1, 2, 3, 4, 5, 8, 12, 26, 27],
-    "bf16": [0, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35],
+    "bf16": [0, 2, 3, 5, 8, 9, 10, 11, 12, 13, 14, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32],
 }
 
 
@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--min-gain", type=float, default=0.004)
     ap.add_argument("--lanes", type=int, default=0, help="0: the table's")
     ap.add_argument("--write", default="")
+    ap.add_argument("--only", default="", help="comma-separated substrings: tune only the signatures containing one of them")
+    ap.add_argument("--tiles", default="", help="comma-separated candidate tile ids (default: the mode's list)")
     a = ap.parse_args()
     B, S = a.batch, a.image_size
     dt = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3, "f32x2": _lib.Y3_DTYPE_F32X2}[a.dtype]
@@ -84,12 +86,16 @@ def main():
     print(f"start: {best:.3f} ms  ({B / best * 1e3:.0f} img/s)", flush=True)
     # The chip warms up over the run (round 3: 10.07 -> 10.17 ms with nothing changed), so a candidate is compared with
     # the CURRENT tile measured right before it, and a winner must win a second, re-measured pair.
+    cands = [int(v) for v in a.tiles.split(",")] if a.tiles else CANDIDATES[a.dtype]
+    only = [v for v in a.only.split(",") if v]
     for sig in sorted(sigs, key=lambda s: -sigs[s]["flops"]):
+        if only and not any(v in sig for v in only):
+            continue
         cur = int(table.get(sig, -1))
         apply(sig, cur)
         ref = measure()
         cand = {}
-        for t in CANDIDATES[a.dtype]:
+        for t in cands:
             if t == cur:
                 continue
             try:

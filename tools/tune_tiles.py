@@ -63,10 +63,6 @@ def main():
                 legal = legal and o.size == 3 and o.stride == 1 and o.src1 < 0 and o.cin == 32 and o.cout % 64 == 0
             if a.dtype == "bf16" and t == 32:   # the weight-resident kernel: 3x3 / stride 1, 32 or 64 input channels, bf16 output
                 legal = legal and o.size == 3 and o.stride == 1 and o.src1 < 0 and o.cin in (32, 64) and o.cout % 64 == 0 and o.dst not in p.outputs
-            if a.dtype == "bf16" and 33 <= t <= 35:   # tap-row reuse: 3x3 / stride 1, Cin % 128 == 0, bf16 output
-                legal = legal and o.size == 3 and o.stride == 1 and o.src1 < 0 and o.cin % 128 == 0 and o.cout % 32 == 0 and o.dst not in p.outputs
-            if a.dtype == "bf16" and t == 36:   # four waves of 128x128: no concat, bf16 output, an even number of K tiles
-                legal = legal and o.src1 < 0 and o.cout % 256 == 0 and (o.size * o.size * o.cin) % 128 == 0 and o.dst not in p.outputs
             ok.append(legal)
             (net.set_tile_x2 if x2 else net.set_tile_x3 if x3 else net.set_tile_bf16 if bf else net.set_tile)(slot, t if legal else -1)
         best = None

@@ -30,7 +30,8 @@ TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (6
          (0, 0, 0, 0),                                      # 25: retired id
          (64, 128, 4, 2), (64, 64, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (256, 32, 4, 2),  # 26..30: LDS-DMA operand loads
          (64, 128, 4, 1), (64, 64, 4, 1),                   # 31, 32: LDS-DMA, single LDS stage
-         (128, 64, 8, 2)]                                   # 33: weight-resident 3x3 / stride 1 / Cin 32 (csrc/conv_res_f32.hip)
+         (128, 64, 8, 2),                                   # 33: weight-resident 3x3 / stride 1 / Cin 32 (csrc/conv_res_f32.hip)
+         (32, 128, 4, 1)]                                   # 34: 32x128 on one row of four waves, LDS-DMA, single stage
 RETIRED_TILES = tuple(i for i, t in enumerate(TILES) if t[0] == 0)   # ids y3_tile_built answers 0 for
 # three-plane (fp32-accurate on bf16 MFMA) kernel tiles: (BM, BN, waves, BK)
 TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), (256, 64, 4, 32),
@@ -55,9 +56,8 @@ TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4
               (128, 128, 4, 64), (128, 64, 4, 64), (64, 128, 4, 64),       # 27..29: tiles 8, 10, 12 on 16x16x32 MFMAs
               (128, 64, 4, 32), (64, 64, 4, 32),                          # 30, 31: LDS-DMA, BK 32, 64 output channels
               (128, 64, 8, 32),                                           # 32: weight-resident 3x3 / stride 1, Cin 32 / 64 (csrc/conv_res_bf16.hip)
-              (256, 256, 16, 64), (128, 128, 4, 64), (64, 128, 4, 64),    # 33..35: 3x3 / stride 1, Cin % 128 == 0, tap-row reuse (csrc/conv_bf16_rs.hip)
-              (256, 256, 4, 64)]                                          # 36: 256x256 on four waves of 128x128, software-pipelined (csrc/conv_bf16_w4.hip)
-TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 else "") + ("res" if i == 33 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
+              (0, 0, 0, 64), (0, 0, 0, 64), (0, 0, 0, 64), (0, 0, 0, 64)]  # 33..36: retired in round 5 (tap-row reuse, the four-wave 256x256 tile: no plan selected them)
+TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 or i == 34 else "") + ("res" if i == 33 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
 
 
 class Y3Error(RuntimeError):
@@ -126,6 +126,7 @@ SYMBOLS = {
     "y3_allgather_results": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
 }
 Y3_COMM_ID_BYTES = 128
+Y3_ERR_INVALID, Y3_ERR_HIP, Y3_ERR_OOM, Y3_ERR_STATE, Y3_ERR_NODEVICE, Y3_ERR_COMM, Y3_ERR_INTERNAL = -1, -2, -3, -4, -5, -6, -7   # include/y3.h
 
 _lib = None
 

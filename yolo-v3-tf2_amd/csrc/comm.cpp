@@ -14,14 +14,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 
 #include "../../include/y3.h"
 
 namespace y3 {
-int fail_msg(int code, const char *fmt, ...);   // y3_api.cpp: sets the thread-local error string, returns code
+int fail_msg(int code, const char *fmt, ...) noexcept;   // y3_api.cpp: fills the thread-local error buffer, returns code
+int on_exception(const char *who) noexcept;              // y3_api.cpp: the exception barrier of the C ABI (rethrows and classifies)
+bool test_fail_alloc() noexcept;                         // y3_api.cpp: Y3_TEST_FAIL_ALLOC=1 (tests)
 }
+#define Y3_CATCH(who) catch (...) { return y3::on_exception(who); }
 
 namespace {
 
@@ -91,7 +96,7 @@ struct y3_comm {
 extern "C" {
 
 y3_status y3_comm_get_unique_id(void *id_out)
-{
+try {
     static_assert(Y3_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
     if (!id_out) return y3::fail_msg(Y3_ERR_INVALID, "y3_comm_get_unique_id: null argument");
     Rccl &r = rccl();
@@ -101,30 +106,28 @@ y3_status y3_comm_get_unique_id(void *id_out)
     memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
     return Y3_OK;
 }
+Y3_CATCH("y3_comm_get_unique_id")
 
 y3_status y3_comm_init_rank(const void *id, int world_size, int rank, y3_comm **out)
-{
+try {
     if (!id || !out || world_size < 1 || rank < 0 || rank >= world_size)
         return y3::fail_msg(Y3_ERR_INVALID, "y3_comm_init_rank: bad argument");
+    if (y3::test_fail_alloc()) throw std::bad_alloc();   // tests only: the allocation below failing
     Rccl &r = rccl();
     if (!r.error.empty()) return y3::fail_msg(Y3_ERR_COMM, "%s", r.error.c_str());
-    y3_comm *c = new y3_comm();
-    if (hipGetDevice(&c->device) != hipSuccess) {
-        delete c;
-        return y3::fail_msg(Y3_ERR_NODEVICE, "y3_comm_init_rank: no HIP device");
-    }
+    std::unique_ptr<y3_comm> c(new y3_comm());
+    if (hipGetDevice(&c->device) != hipSuccess) return y3::fail_msg(Y3_ERR_NODEVICE, "y3_comm_init_rank: no HIP device");
     ncclUniqueId uid;
     memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
     ncclResult_t e = r.CommInitRank(&c->comm, world_size, uid, rank);
-    if (e != ncclSuccess) {
-        delete c;
+    if (e != ncclSuccess)
         return y3::fail_msg(Y3_ERR_COMM, "ncclCommInitRank(world %d, rank %d): %s", world_size, rank, r.GetErrorString(e));
-    }
     c->world = world_size;
     c->rank = rank;
-    *out = c;
+    *out = c.release();
     return Y3_OK;
 }
+Y3_CATCH("y3_comm_init_rank")
 
 void y3_comm_destroy(y3_comm *comm)
 {
@@ -144,7 +147,7 @@ y3_status y3_comm_info(const y3_comm *comm, int32_t *world_size, int32_t *rank)
 
 y3_status y3_allgather_results(y3_comm *comm, const void *packed_dev, const int32_t *num_valid_dev, int batch,
                                int max_boxes, void *packed_all_dev, int32_t *num_valid_all_dev, void *stream)
-{
+try {
     if (!comm || !packed_dev || !num_valid_dev || !packed_all_dev || !num_valid_all_dev || batch <= 0 || max_boxes <= 0)
         return y3::fail_msg(Y3_ERR_INVALID, "y3_allgather_results: bad argument");
     Rccl &r = rccl();
@@ -159,5 +162,6 @@ y3_status y3_allgather_results(y3_comm *comm, const void *packed_dev, const int3
                             r.GetErrorString(e1 != ncclSuccess ? e1 : e2 != ncclSuccess ? e2 : e3));
     return Y3_OK;
 }
+Y3_CATCH("y3_allgather_results")
 
 }  // extern "C"

@@ -447,8 +447,11 @@ static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
     {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64}, {128, 128, 4, 64}, {128, 64, 4, 64}, {64, 128, 4, 64},  // 24..29: 16x16x32 MFMAs
     {128, 64, 4, 32}, {64, 64, 4, 32},                            // 30, 31: LDS-DMA with BK = 32 for the Cin = 32 / Cout = 64 layer
     {128, 64, 8, 32},                                             // 32: weight-resident 3x3 / stride 1, Cin = 32 / 64 (conv_res_bf16.hip): 4 x 32 pixels x 64 channels per workgroup tile
-    {256, 256, 16, 64}, {128, 128, 4, 64}, {64, 128, 4, 64},      // 33..35: 3x3 / stride 1 with tap-row reuse (conv_bf16_rs.hip), the shapes of tiles 24, 27, 29
-    {256, 256, 4, 64},                                             // 36: 256x256 on four waves of 128x128, software-pipelined (conv_bf16_w4.hip)
+    // 33..35 (3x3 / stride 1 with tap-row reuse: one activation tile per kernel row, taps from shifted LDS rows) and 36 (256x256 on four waves
+    // of 128x128, hand-pipelined): retired in round 5.  Both were parity-green and neutral / slower in the two-lane step and no plan selected
+    // them (profiles/r04_ab_bf16_rs.txt, r04_tile_sweep_bf16_rs_b64.txt, r04_tile_sweep_bf16_w4.txt, r04_bench_bf16_b128_s416_table_{rs,w4}.json);
+    // the code is in the history (csrc/conv_bf16_rs.hip, csrc/conv_bf16_w4.hip at commit 1777145).
+    {0, 0, 0, 64}, {0, 0, 0, 64}, {0, 0, 0, 64}, {0, 0, 0, 64},
 };
 
 #ifdef Y3_PHASE_STAMPS
@@ -474,7 +477,7 @@ static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
     const size_t lds = stages > ctile ? stages : ctile;
     auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, DMA, MINW, M16>;
     static LdsAttrOnce attr;  // per instantiation
-    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds, a.device); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }
@@ -495,8 +498,6 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
     if (a.dst == nullptr && a.dec.boxes == nullptr) return hipErrorInvalidValue;
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
     if (tile == 32) return (!out_f32 && conv_res_bf16_fits(a)) ? launch_conv_res_bf16(a, s) : hipErrorInvalidValue;
-    if (tile == 36) return (!out_f32 && conv_bf16_w4_fits(a)) ? launch_conv_bf16_w4(a, s) : hipErrorInvalidValue;
-    if (tile >= 33 && tile <= 35) return (!out_f32 && conv_bf16_rs_fits(a)) ? launch_conv_bf16_rs(a, tile, s) : hipErrorInvalidValue;
     switch (tile) {
         case 0: return launch_tb<2, 2, 2, 2, 64>(a, out_f32, s);
         case 1: return launch_tb<2, 2, 4, 2, 64>(a, out_f32, s);

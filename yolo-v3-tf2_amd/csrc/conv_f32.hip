@@ -471,6 +471,7 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {64, 128, 4, 2}, {64, 64, 4, 2}, {128, 128, 4, 2}, {128, 64, 4, 2}, {256, 32, 4, 2},  // 26..30: LDS-DMA loads
     {64, 128, 4, 1}, {64, 64, 4, 1},                     // 31, 32: LDS-DMA, single stage
     {128, 64, 8, 2},                                     // 33: weight-resident 3x3 / stride 1 / Cin = 32 (conv_res_f32.hip): 8 x 16 pixels x 64 channels per workgroup tile
+    {32, 128, 4, 1},                                     // 34: 32x128 (one row of four waves), LDS-DMA, single stage: twice the pixel tiles of 64x128 for the 13^2 / 26^2 1x1 layers (VERDICT r04 #3b)
 };
 
 #ifdef Y3_PHASE_STAMPS
@@ -494,7 +495,7 @@ static hipError_t launch_k(const ConvArgs &a_in, hipStream_t s)
     const size_t lds = STAGES * (size_t)(BM + BN) * (DMA ? BK : LDS_ROW_PADDED) * sizeof(float);
     auto k = conv_f32_mfma<TM, TN, WR, WC, CONCAT, STAGES, MINW, DMA>;
     static LdsAttrOnce attr;  // per instantiation
-    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds, a.device); e != hipSuccess) return e;
     int grid = tilesM * tilesN;
     if (a.xcd_gn > 0) {
         if (8 % a.xcd_gn || tilesN % a.xcd_gn) return hipErrorInvalidValue;
@@ -543,6 +544,7 @@ hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
         case 30: return a.src1 ? launch_k<2, 1, 4, 1, true, 2, 1, 1>(a, s) : launch_k<2, 1, 4, 1, false, 2, 1, 1>(a, s);  // 256x32
         case 31: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 4, 1>(a, s);  // 64x128, 1 stage
         case 32: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 4, 1>(a, s);  // 64x64, 1 stage
+        case 34: return a.src1 ? launch_k<1, 1, 1, 4, true, 1, 4, 1>(a, s) : launch_k<1, 1, 1, 4, false, 1, 4, 1>(a, s);  // 32x128, 1 stage
         case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 3>(a, s);
         case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 4>(a, s);
         default: return hipErrorInvalidValue;

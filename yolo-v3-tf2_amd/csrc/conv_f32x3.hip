@@ -508,7 +508,7 @@ static hipError_t launch_kx(const ConvArgs &a, hipStream_t s)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto k = conv_f32x3_mfma<NPL, TM, TN, WR, WC, BK, CONCAT, OUT_F32, STAGES, VAR>;
     static LdsAttrOnce attr;  // per instantiation
-    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds); e != hipSuccess) return e;
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds, a.device); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
     return hipGetLastError();
 }

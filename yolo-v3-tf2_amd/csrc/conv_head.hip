@@ -131,7 +131,7 @@ hipError_t launch_conv_head_decode_f32(const ConvArgs &a, hipStream_t s)
 {
     if (!conv_head_decode_f32_fits(a)) return hipErrorInvalidValue;
     static LdsAttrOnce attr;
-    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv_head_decode_f32), (int)HLDS); e != hipSuccess) return e;
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv_head_decode_f32), (int)HLDS, a.device); e != hipSuccess) return e;
     hipLaunchKernelGGL(conv_head_decode_f32, dim3((a.M + HBM - 1) / HBM), dim3(HNT), HLDS, s, a);
     return hipGetLastError();
 }

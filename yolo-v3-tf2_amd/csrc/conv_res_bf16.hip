@@ -252,21 +252,18 @@ hipError_t launch_conv_res_bf16(const ConvArgs &a, hipStream_t s)
     if (!conv_res_bf16_fits(a)) return hipErrorInvalidValue;
     const int tiles_x = (a.Wo + RTW - 1) / RTW, tiles_y = (a.Ho + RTH - 1) / RTH;
     const int n_spatial = a.B * tiles_y * tiles_x, slices = a.Cout / RSLICE;
-    int dev = 0, cus = 0;
-    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-    if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
-    if (cus <= 0) cus = 256;
+    const int cus = a.n_cus > 0 ? a.n_cus : 256;                // read once at plan time (y3_net_plan): no runtime query on the enqueue path
     int per_slice = cus / slices;                               // one persistent workgroup per CU (the resident weights + two patches fill its LDS)
     if (per_slice < 1) per_slice = 1;
     if (per_slice > n_spatial) per_slice = n_spatial;
     const int grid = per_slice * slices;
     if (a.Cin == 32) {
         static LdsAttrOnce attr;
-        if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv3x3_res_bf16<32>), ResGeom<32>::LDS_BYTES); e != hipSuccess) return e;
+        if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv3x3_res_bf16<32>), ResGeom<32>::LDS_BYTES, a.device); e != hipSuccess) return e;
         hipLaunchKernelGGL(conv3x3_res_bf16<32>, dim3(grid), dim3(RNT), ResGeom<32>::LDS_BYTES, s, a, tiles_x, tiles_y, n_spatial, slices);
     } else {
         static LdsAttrOnce attr;
-        if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv3x3_res_bf16<64>), ResGeom<64>::LDS_BYTES); e != hipSuccess) return e;
+        if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv3x3_res_bf16<64>), ResGeom<64>::LDS_BYTES, a.device); e != hipSuccess) return e;
         hipLaunchKernelGGL(conv3x3_res_bf16<64>, dim3(grid), dim3(RNT), ResGeom<64>::LDS_BYTES, s, a, tiles_x, tiles_y, n_spatial, slices);
     }
     return hipGetLastError();

@@ -216,15 +216,12 @@ hipError_t launch_conv_res_f32(const ConvArgs &a, hipStream_t s)
     if (!conv_res_f32_fits(a)) return hipErrorInvalidValue;
     const int tiles_x = (a.Wo + FTW - 1) / FTW, tiles_y = (a.Ho + FTH - 1) / FTH;
     const int n_spatial = a.B * tiles_y * tiles_x, slices = a.Cout / FSLICE;
-    int dev = 0, cus = 0;
-    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-    if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
-    if (cus <= 0) cus = 256;
+    const int cus = a.n_cus > 0 ? a.n_cus : 256;   // read once at plan time (y3_net_plan): no runtime query on the enqueue path
     int per_slice = cus / slices;
     if (per_slice < 1) per_slice = 1;
     if (per_slice > n_spatial) per_slice = n_spatial;
     static LdsAttrOnce attr;
-    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv3x3_res_f32), FLDS_BYTES); e != hipSuccess) return e;
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv3x3_res_f32), FLDS_BYTES, a.device); e != hipSuccess) return e;
     hipLaunchKernelGGL(conv3x3_res_f32, dim3(per_slice * slices), dim3(FNT), FLDS_BYTES, s, a, tiles_x, tiles_y, n_spatial, slices);
     return hipGetLastError();
 }

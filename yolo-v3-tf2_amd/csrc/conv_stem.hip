@@ -358,17 +358,9 @@ hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s)
     p.tiles_x = (a.S / 2) / TW;
     p.n_tiles = a.B * p.tiles_y * p.tiles_x;
     static LdsAttrOnce attr;
-    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv_stem_f32), LDS_BYTES); e != hipSuccess) return e;
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!cus[dev]) {
-        int n = 0;
-        if (hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
-        cus[dev] = n > 0 ? n : 256;
-    }
-    const int grid = p.n_tiles < cus[dev] ? p.n_tiles : cus[dev];   // one persistent workgroup per CU
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv_stem_f32), LDS_BYTES, a.device); e != hipSuccess) return e;
+    const int cus = a.n_cus > 0 ? a.n_cus : 256;                // read once at plan time (y3_net_plan)
+    const int grid = p.n_tiles < cus ? p.n_tiles : cus;         // one persistent workgroup per CU
     hipLaunchKernelGGL(conv_stem_f32, dim3(grid), dim3(NT), LDS_BYTES, s, p);
     return hipGetLastError();
 }
@@ -684,11 +676,8 @@ hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s)
     p.tiles_x = (a.S / 2) / TW;
     p.n_tiles = a.B * p.tiles_y * p.tiles_x;
     static LdsAttrOnce attr;
-    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv_stem_bf16), LDS_BYTES_B); e != hipSuccess) return e;
-    int dev = 0, cus = 0;
-    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-    if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
-    if (cus <= 0) cus = 256;
+    if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(conv_stem_bf16), LDS_BYTES_B, a.device); e != hipSuccess) return e;
+    const int cus = a.n_cus > 0 ? a.n_cus : 256;                // read once at plan time (y3_net_plan)
     const int grid = p.n_tiles < 2 * cus ? p.n_tiles : 2 * cus;   // two persistent workgroups per CU
     hipLaunchKernelGGL(conv_stem_bf16, dim3(grid), dim3(NT), LDS_BYTES_B, s, p);
     return hipGetLastError();

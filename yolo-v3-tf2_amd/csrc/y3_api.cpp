@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <string>
+#include <exception>
+#include <memory>
+#include <new>
 #include <vector>
 
 #include "../../include/y3.h"
@@ -17,16 +19,16 @@
 
 namespace {
 
-thread_local std::string g_err;
+// The last error of this thread: a fixed buffer, so that reporting a failure allocates nothing and cannot itself throw
+// (include/y3.h: no entry point throws or aborts -- not even while it reports that the host ran out of memory).
+thread_local char g_err[512] = "";
 
-int fail(int code, const char *fmt, ...)
+int fail(int code, const char *fmt, ...) noexcept
 {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
-    g_err = buf;
     return code;
 }
 
@@ -34,17 +36,41 @@ int fail(int code, const char *fmt, ...)
 
 namespace y3 {
 // for the other translation units of the library (comm.cpp)
-int fail_msg(int code, const char *fmt, ...)
+int fail_msg(int code, const char *fmt, ...) noexcept
 {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
-    g_err = buf;
     return code;
 }
+
+// The exception barrier of the C ABI.  Every extern "C" entry point that can reach an allocation (std::vector, new, std::string)
+// is a function-try-block ending in Y3_CATCH: a C++ exception becomes a status + message instead of crossing the boundary and
+// terminating the host process (a ctypes / cgo / JNI caller has no handler for it).
+int on_exception(const char *who) noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail_msg(Y3_ERR_OOM, "%s: out of host memory (std::bad_alloc)", who);
+    } catch (const std::exception &e) {
+        return fail_msg(Y3_ERR_INTERNAL, "%s: C++ exception: %s", who, e.what());
+    } catch (...) {
+        return fail_msg(Y3_ERR_INTERNAL, "%s: unknown C++ exception", who);
+    }
+}
+
+// Test hook (tests/test_abi.py): Y3_TEST_FAIL_ALLOC=1 makes the object allocations of y3_net_create / y3_comm_init_rank fail the
+// way operator new does; read on every call so that a test can switch it on and off inside one process.
+bool test_fail_alloc() noexcept
+{
+    const char *e = getenv("Y3_TEST_FAIL_ALLOC");
+    return e && e[0] == '1';
+}
 }  // namespace y3
+
+#define Y3_CATCH(who) catch (...) { return y3::on_exception(who); }
 
 namespace {
 
@@ -108,6 +134,7 @@ constexpr int Y3_MAX_OUTPUT_BOXES = 1024;   // upper bound of max_output_size (y
 
 struct y3_net {
     int device = 0;
+    int n_cus = 0;                 // compute units of `device`, read once by y3_net_plan (grids of the persistent kernels)
     std::vector<y3_tensor_desc> tensors;
     std::vector<Op> ops;
     std::vector<ConvSlot> convs;
@@ -394,11 +421,23 @@ static bool stem_conv2_applicable(const y3_net *net)
     return true;
 }
 
+// Does this conv's launch write an fp32 net output directly (bf16 / plane-split plans)?  Mirrors the `staged` rule of y3_net_plan: an
+// output that another op reads, or that a shortcut / first-layer conv writes, stays in the arena in the mode's format instead.
+static bool writes_f32_output(const y3_net *net, const ConvSlot &c)
+{
+    const int t = c.d.dst;
+    if (t != net->outputs[0] && t != net->outputs[1] && t != net->outputs[2]) return false;
+    if (c.d.residual >= 0 || c.first_layer) return false;
+    for (const ConvSlot &o : net->convs)
+        if (o.d.src0 == t || o.d.src1 == t || o.d.residual == t) return false;
+    return true;
+}
+
 extern "C" {
 
 int y3_version(void) { return 100; }
 
-const char *y3_last_error(void) { return g_err.c_str(); }
+const char *y3_last_error(void) { return g_err; }
 
 int y3_device_count(void)
 {
@@ -421,14 +460,12 @@ int y3_tile_built(int dtype, int tile)
 y3_status y3_net_create(const y3_tensor_desc *tensors, int n_tensors, const int32_t *op_kinds, int n_ops,
                         const y3_conv_desc *convs, int n_convs, const y3_aux_desc *aux, int n_aux, int input_tensor,
                         const int32_t outputs[3], int nclasses, y3_net **out)
-{
-    if (!tensors || !op_kinds || !convs || !outputs || !out || n_tensors <= 0 || n_ops <= 0)
-        return fail(Y3_ERR_INVALID, "y3_net_create: null or empty argument");
-    auto net = new y3_net();
-    if (hipGetDevice(&net->device) != hipSuccess) {
-        delete net;
-        return fail(Y3_ERR_NODEVICE, "y3_net_create: no HIP device");
-    }
+try {
+    if (!tensors || !op_kinds || !convs || !outputs || !out || n_tensors <= 0 || n_ops <= 0 || n_convs < 0 || n_aux < 0)
+        return fail(Y3_ERR_INVALID, "y3_net_create: null, empty or negative-count argument");
+    if (y3::test_fail_alloc()) throw std::bad_alloc();   // tests only: the allocation below failing
+    std::unique_ptr<y3_net> net(new y3_net());           // released to the caller on success only: no path leaks it, thrown ones included
+    if (hipGetDevice(&net->device) != hipSuccess) return fail(Y3_ERR_NODEVICE, "y3_net_create: no HIP device");
     net->tensors.assign(tensors, tensors + n_tensors);
     net->aux.assign(aux, aux + (aux ? n_aux : 0));
     net->convs.resize(n_convs);
@@ -447,7 +484,6 @@ y3_status y3_net_create(const y3_tensor_desc *tensors, int n_tensors, const int3
         if (!c.first_layer && d.cin % 32) err = 6;
         if (d.cout <= 0 || d.out_div != d.in_div * d.stride) err = err ? err : 7;
         if (err) {
-            delete net;
             return fail(Y3_ERR_INVALID, "y3_net_create: conv %d unsupported or inconsistent (check %d)", i, err);
         }
         c.cout_pad = (d.cout + 31) / 32 * 32;
@@ -457,19 +493,18 @@ y3_status y3_net_create(const y3_tensor_desc *tensors, int n_tensors, const int3
     int ci = 0, ai = 0;
     for (int i = 0; i < n_ops; ++i) {
         if (op_kinds[i] == 0) {
-            if (ci >= n_convs) { delete net; return fail(Y3_ERR_INVALID, "y3_net_create: more conv ops than descriptors"); }
+            if (ci >= n_convs) { return fail(Y3_ERR_INVALID, "y3_net_create: more conv ops than descriptors"); }
             net->ops.push_back({0, ci++});
         } else {
-            if (ai >= n_aux) { delete net; return fail(Y3_ERR_INVALID, "y3_net_create: more aux ops than descriptors"); }
+            if (ai >= n_aux) { return fail(Y3_ERR_INVALID, "y3_net_create: more aux ops than descriptors"); }
             net->ops.push_back({1, ai++});
         }
     }
-    if (bad_t(input_tensor)) { delete net; return fail(Y3_ERR_INVALID, "y3_net_create: bad input tensor"); }
+    if (bad_t(input_tensor)) { return fail(Y3_ERR_INVALID, "y3_net_create: bad input tensor"); }
     net->input_tensor = input_tensor;
     for (int i = 0; i < 3; ++i) {
         // nclasses == 0: raw feature outputs (layer tests); otherwise the yolo head layout is enforced
         if (bad_t(outputs[i]) || (nclasses > 0 && tensors[outputs[i]].channels != 3 * (5 + nclasses))) {
-            delete net;
             return fail(Y3_ERR_INVALID, "y3_net_create: output %d must have 3*(5+nclasses) channels", i);
         }
         net->outputs[i] = outputs[i];
@@ -478,9 +513,10 @@ y3_status y3_net_create(const y3_tensor_desc *tensors, int n_tensors, const int3
     net->tdev.assign(n_tensors, nullptr);
     net->tbytes.assign(n_tensors, 0);
     net->tblock.assign(n_tensors, 0);
-    *out = net;
+    *out = net.release();
     return Y3_OK;
 }
+Y3_CATCH("y3_net_create")
 
 void y3_net_destroy(y3_net *net)
 {
@@ -508,7 +544,7 @@ void y3_net_destroy(y3_net *net)
 
 y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const float *gamma, const float *beta,
                                   const float *mean, const float *var, const float *bias, float eps)
-{
+try {
     if (!net || slot < 0 || slot >= (int)net->convs.size() || !w)
         return fail(Y3_ERR_INVALID, "y3_net_set_conv_weights: bad slot or null weights");
     ConvSlot &c = net->convs[slot];
@@ -601,9 +637,10 @@ y3_status y3_net_set_conv_weights(y3_net *net, int slot, const float *w, const f
     c.loaded = true;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_conv_weights")
 
 y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
-{
+try {
     if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::TILE_COUNT)
         return fail(Y3_ERR_INVALID, "y3_net_set_tile: bad argument");
     ConvSlot &c = net->convs[slot];
@@ -618,31 +655,34 @@ y3_status y3_net_set_tile(y3_net *net, int slot, int tile)
     c.tile = tile;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_tile")
 
 y3_status y3_net_set_tile_bf16(y3_net *net, int slot, int tile)
-{
+try {
     if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::BF16_TILE_COUNT)
         return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: bad argument");
     ConvSlot &c = net->convs[slot];
     if (tile >= 0) {
         if (!y3::conv_bf16_tile_built(tile))
-            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile id %d is retired (the pipelined tile of round 2; y3_tile_built)", tile);
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile id %d is retired (20: the pipelined tile of round 2; 33..36: tap-row reuse and the four-wave tile of round 4; y3_tile_built)", tile);
         y3::TileInfo s = y3::conv_bf16_tile_info(tile);
         if (c.first_layer || c.cout_pad % s.bn || c.d.cin % s.stages || (c.d.src1 >= 0 && c.d.c0 % s.stages))
             return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile does not fit this conv");
         if (tile == 32 && !(c.d.size == 3 && c.d.stride == 1 && c.d.src1 < 0 && (c.d.cin == 32 || c.d.cin == 64) && c.d.cout % 64 == 0))
             return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile 32 (weight-resident) needs a 3x3 / stride-1 conv with 32 or 64 input channels and Cout %% 64 == 0");
-        if (tile == 36 && !(c.d.src1 < 0 && c.cout_pad == c.d.cout && (c.d.size * c.d.size * c.d.cin) % 128 == 0))
-            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile 36 (four waves of 128x128) needs a conv without a concat source, unpadded Cout %% 256 == 0 and an even number of 64-wide K tiles");
-        if (tile >= 33 && tile <= 35 && !(c.d.size == 3 && c.d.stride == 1 && c.d.src1 < 0 && c.d.cin % 128 == 0 && c.cout_pad == c.d.cout))
-            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tiles 33..35 (tap-row reuse) need a 3x3 / stride-1 conv with Cin %% 128 == 0 and unpadded Cout");
+        // tile 32 stores bf16 only: a conv whose destination is a net output that the forward hands over as fp32 straight from the launch
+        // (not read again inside the net, no shortcut: y3_net_plan does not stage it) cannot take it -- refused here, by name, instead of a
+        // launch error in the forward
+        if (tile == 32 && writes_f32_output(net, c))
+            return fail(Y3_ERR_INVALID, "y3_net_set_tile_bf16: tile 32 (weight-resident) stores bf16 only; conv %d writes an fp32 net output", slot);
     }
     c.tile_bf16 = tile;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_tile_bf16")
 
 y3_status y3_net_set_tile_x3(y3_net *net, int slot, int tile)
-{
+try {
     if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::X3_TILE_COUNT || (tile >= 0 && !y3::conv_x3_tile_built(tile)))
         return fail(Y3_ERR_INVALID, "y3_net_set_tile_x3: bad argument");
     ConvSlot &c = net->convs[slot];
@@ -654,9 +694,10 @@ y3_status y3_net_set_tile_x3(y3_net *net, int slot, int tile)
     c.tile_x3 = tile;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_tile_x3")
 
 y3_status y3_net_set_tile_x2(y3_net *net, int slot, int tile)
-{
+try {
     if (!net || slot < 0 || slot >= (int)net->convs.size() || tile >= y3::X3_TILE_COUNT)
         return fail(Y3_ERR_INVALID, "y3_net_set_tile_x2: bad argument");
     ConvSlot &c = net->convs[slot];
@@ -669,16 +710,18 @@ y3_status y3_net_set_tile_x2(y3_net *net, int slot, int tile)
     c.tile_x2 = tile;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_tile_x2")
 
 y3_status y3_net_set_lanes(y3_net *net, int lanes)
-{
+try {
     if (!net || lanes < 1 || lanes > Y3_MAX_LANES) return fail(Y3_ERR_INVALID, "y3_net_set_lanes: lanes must be in [1,%d]", Y3_MAX_LANES);
     net->lanes = lanes;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_lanes")
 
 y3_status y3_net_set_stem_fusion(y3_net *net, int on)
-{
+try {
     if (!net || on < 0 || on > 2) return fail(Y3_ERR_INVALID, "y3_net_set_stem_fusion: argument must be 0, 1 or 2");
     net->stem_mode = on;
     net->stem_mode_set = true;
@@ -689,36 +732,41 @@ y3_status y3_net_set_stem_fusion(y3_net *net, int on)
     }
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_stem_fusion")
 
 y3_status y3_net_set_k_chunk(y3_net *net, int channels)
-{
+try {
     if (!net || channels < -1 || (channels > 0 && channels % 32)) return fail(Y3_ERR_INVALID, "y3_net_set_k_chunk: -1, 0 or a multiple of 32 channels");
     net->k_chunk = channels;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_k_chunk")
 
 y3_status y3_net_set_xcd_mode(y3_net *net, int mode)
-{
+try {
     if (!net || mode < 0 || mode > 1) return fail(Y3_ERR_INVALID, "y3_net_set_xcd_mode: mode must be 0 or 1");
     net->xcd_mode = mode;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_xcd_mode")
 
 y3_status y3_net_set_early_chunk(y3_net *net, int n_convs, int chunk_images)
-{
+try {
     if (!net || n_convs < 0 || chunk_images < 0) return fail(Y3_ERR_INVALID, "y3_net_set_early_chunk: bad argument");
     if (n_convs >= (int)net->convs.size()) return fail(Y3_ERR_INVALID, "y3_net_set_early_chunk: n_convs must leave at least one conv for the full batch");
     net->early_convs = (chunk_images > 0) ? n_convs : 0;
     net->early_chunk = (n_convs > 0) ? chunk_images : 0;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_set_early_chunk")
 
 y3_status y3_net_keep_activations(y3_net *net, int keep)
-{
+try {
     if (!net) return fail(Y3_ERR_INVALID, "y3_net_keep_activations: null net");
     net->keep_all = keep ? 1 : 0;
     return Y3_OK;
 }
+Y3_CATCH("y3_net_keep_activations")
 
 static void detect_layout(const y3_net *net, int batch, size_t off[9], size_t *n_boxes, int32_t gs[3], size_t gelems[3]);
 
@@ -735,7 +783,7 @@ static y3_status ensure_lanes(y3_net *net)
 }
 
 y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
-{
+try {
     if (!net || max_batch <= 0 || image_size <= 0) return fail(Y3_ERR_INVALID, "y3_net_plan: bad argument");
     if (dtype != Y3_DTYPE_F32 && dtype != Y3_DTYPE_BF16 && dtype != Y3_DTYPE_F32X3 && dtype != Y3_DTYPE_F32X2)
         return fail(Y3_ERR_INVALID, "y3_net_plan: unknown dtype %d", dtype);
@@ -747,6 +795,11 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
                 return fail(Y3_ERR_INVALID, "y3_net_plan: conv %zu has a BN-scaled weight outside the fp16 range (|w| >= 65504); "
                                             "the two-plane mode cannot represent it, use Y3_DTYPE_F32 or Y3_DTYPE_F32X3", i);
     Y3_ENTER_DEVICE(net);
+    if (net->n_cus <= 0) {   // once per net: the launch path itself makes no device query
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, net->device));
+        net->n_cus = cus > 0 ? cus : 256;
+    }
     free_plan(net);
     net->max_batch = max_batch;
     net->image_size = image_size;
@@ -856,6 +909,7 @@ y3_status y3_net_plan(y3_net *net, int max_batch, int image_size, int dtype)
     }
     return Y3_OK;
 }
+Y3_CATCH("y3_net_plan")
 
 // byte offsets of the y3_net_detect scratch for `batch` images (and the total in [8])
 static void detect_layout(const y3_net *net, int batch, size_t off[9], size_t *n_boxes, int32_t gs[3], size_t gelems[3])
@@ -968,6 +1022,8 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
             a.dst_bytes = (unsigned)bytes(d.dst);
             a.xcd_gn = 0;
             a.k_chunk = 0;
+            a.n_cus = net->n_cus;
+            a.device = net->device;
             a.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : (net->clk_conv == -2 && net->clk_stamps) ? net->clk_stamps + 8 * o.index : nullptr;   // fp32 MFMA kernel and stem only
             int head = -1;   // fused decode: which output this conv produces (its grid is then not written)
             if (net->fuse)
@@ -1005,6 +1061,8 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 sa.leaky1 = d.leaky;
                 sa.img_bytes = (unsigned)bytes(c0.d.src0);
                 sa.dst_bytes = a.dst_bytes;
+                sa.device = net->device;
+                sa.n_cus = net->n_cus;
                 sa.clk_stamps = (net->clk_conv == o.index) ? net->clk_stamps : (net->clk_conv == -2 && net->clk_stamps) ? net->clk_stamps + 8 * o.index : nullptr;
                 if (net->stem_conv2) {
                     const ConvSlot &c2 = net->convs[net->ops[2].index];
@@ -1164,12 +1222,21 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
         // tools/timeline_dump.py shows lane 0 four kernels ahead), and a start offset between the lanes only costs
         // (profiles/r03_ab_lane_stagger.txt).  A captured forward replays with both branches released at once either way.
         const int n_ops = (int)net->ops.size();
-        for (int oi = 0; oi < n_ops; ++oi)
+        // Y3_LANE_STAGGER=k (tools: VERDICT r04 #3a): lane l starts when lane l - 1 is k ops into the list (a stream wait on an event
+        // recorded behind that op), so that one lane's short 1x1 launches run beside the other lane's 3x3 K loops.  0 / unset: both
+        // lanes released at once (what ships; profiles/r03_ab_lane_stagger.txt, r05_ab_f32_lane_stagger.txt)
+        static const int stagger = [] { const char *e = getenv("Y3_LANE_STAGGER"); return e ? atoi(e) : 0; }();
+        const int k = (stagger > 0 && stagger < n_ops) ? stagger : 0;
+        for (int oi = 0; oi < n_ops + k * (lanes - 1); ++oi)
             for (int l = 0; l < lanes; ++l) {
                 const int nb = start[l + 1] - start[l];
-                if (nb <= 0) continue;
-                y3_status st = run_slice(net, images, grids, start[l], nb, net->lane_stream[l], nullptr, 0, l, lanes, oi, oi + 1);
+                const int op = oi - k * l;
+                if (nb <= 0 || op < 0 || op >= n_ops) continue;
+                if (k && l > 0 && op == 0) HIP_TRY(hipStreamWaitEvent(net->lane_stream[l], net->join_ev[l - 1], 0));
+                y3_status st = run_slice(net, images, grids, start[l], nb, net->lane_stream[l], nullptr, 0, l, lanes, op, op + 1);
                 if (st != Y3_OK) return st;
+                // (join_ev[l] is re-recorded at the end of the lane below: an event names its latest record only for waits enqueued after it)
+                if (k && l + 1 < lanes && op == k - 1) HIP_TRY(hipEventRecord(net->join_ev[l], net->lane_stream[l]));
             }
     }
     for (int l = 0; l < lanes; ++l) {
@@ -1181,24 +1248,32 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
 }
 
 y3_status y3_net_forward(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], void *stream)
-{
+try {
     return run(net, images_dev, batch, grids_dev, (hipStream_t)stream, nullptr, 0);
 }
+Y3_CATCH("y3_net_forward")
 
 y3_status y3_net_profile_convs(y3_net *net, const float *images_dev, int batch, float *ms_out, int n, void *stream)
-{
+try {
     if (!net || !ms_out) return fail(Y3_ERR_INVALID, "y3_net_profile_convs: bad argument");
     // head grids go to scratch owned by this call
+    if (!net->image_size || batch <= 0) return fail(Y3_ERR_STATE, "y3_net_profile_convs: call y3_net_plan first (and batch > 0)");
+    Y3_ENTER_DEVICE(net);
     float *g[3] = {nullptr, nullptr, nullptr};
     for (int i = 0; i < 3; ++i) {
         const int sp = spatial(net, net->outputs[i]);
-        HIP_TRY(hipMalloc(&g[i], (size_t)batch * sp * sp * net->tensors[net->outputs[i]].channels * sizeof(float)));
+        hipError_t e = hipMalloc(&g[i], (size_t)batch * sp * sp * net->tensors[net->outputs[i]].channels * sizeof(float));
+        if (e != hipSuccess) {
+            for (int k = 0; k < i; ++k) (void)hipFree(g[k]);
+            return fail(Y3_ERR_OOM, "y3_net_profile_convs: hipMalloc: %s", hipGetErrorString(e));
+        }
     }
     y3_status st = run(net, images_dev, batch, g, (hipStream_t)stream, ms_out, n);
     (void)hipStreamSynchronize((hipStream_t)stream);
     for (int i = 0; i < 3; ++i) (void)hipFree(g[i]);
     return st;
 }
+Y3_CATCH("y3_net_profile_convs")
 
 namespace {
 // can conv slot i of this plan carry the clock stamps?  The fp32 MFMA kernel (fp32 plans) and the fused stem kernel do.
@@ -1217,17 +1292,18 @@ y3_status measure_sclk_impl(y3_net *net, const float *images_dev, int batch, flo
 
 y3_status y3_net_measure_sclk_conv(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
                                    int conv, float *mhz_out, void *stream)
-{
+try {
     if (!net || !mhz_out || forwards < 1 || conv < 0 || conv >= (int)net->convs.size())
         return fail(Y3_ERR_INVALID, "y3_net_measure_sclk_conv: bad argument");
     if (!conv_carries_stamps(net, (size_t)conv))
         return fail(Y3_ERR_STATE, "y3_net_measure_sclk_conv: the launch of conv %d carries no clock stamps in this plan", conv);
     return measure_sclk_impl(net, images_dev, batch, grids_dev, forwards, conv, mhz_out, stream);
 }
+Y3_CATCH("y3_net_measure_sclk_conv")
 
 y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
                               float *mhz_out, void *stream)
-{
+try {
     if (!net || !mhz_out || forwards < 1) return fail(Y3_ERR_INVALID, "y3_net_measure_sclk: bad argument");
     // the launch that carries the stamps: the conv with the most FLOPs among those whose kernel has them -- the fp32 MFMA
     // kernel (fp32 plans; a steady-state workgroup of a ~0.8 ms launch) or the fused stem kernel (fp32 and bf16 plans)
@@ -1243,6 +1319,7 @@ y3_status y3_net_measure_sclk(y3_net *net, const float *images_dev, int batch, f
     if (pick < 0) return fail(Y3_ERR_STATE, "y3_net_measure_sclk: no launch of this plan carries clock stamps (fp32 plan or fused stem needed)");
     return measure_sclk_impl(net, images_dev, batch, grids_dev, forwards, pick, mhz_out, stream);
 }
+Y3_CATCH("y3_net_measure_sclk")
 
 namespace {
 // pick >= 0: that conv, *mhz_out one value; pick == -2: every conv that carries stamps, mhz_out / start_us / end_us arrays of
@@ -1307,13 +1384,14 @@ y3_status measure_sclk_impl(y3_net *net, const float *images_dev, int batch, flo
 
 y3_status y3_net_measure_sclk_all(y3_net *net, const float *images_dev, int batch, float *const grids_dev[3], int forwards,
                                   float *mhz_out, double *start_us, double *end_us, void *stream)
-{
+try {
     if (!net || !mhz_out || forwards < 1) return fail(Y3_ERR_INVALID, "y3_net_measure_sclk_all: bad argument");
     return measure_sclk_arrays(net, images_dev, batch, grids_dev, forwards, -2, mhz_out, start_us, end_us, stream);
 }
+Y3_CATCH("y3_net_measure_sclk_all")
 
 y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size_t *n_elems, void *stream)
-{
+try {
     if (!net || t < 0 || t >= (int)net->tensors.size() || !net->image_size)
         return fail(Y3_ERR_INVALID, "y3_net_read_tensor: bad argument");
     const int sp = spatial(net, t);
@@ -1321,6 +1399,7 @@ y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size
     if (n_elems) *n_elems = n;
     if (!dst_dev) return Y3_OK;
     if (!net->tdev[t]) return fail(Y3_ERR_STATE, "y3_net_read_tensor: tensor %d is not held in the arena", t);
+    Y3_ENTER_DEVICE(net);   // the conversion kernels / the copy below read the net's arena: enqueue them on its device
     if (net->dtype == Y3_DTYPE_F32X2) {
         hipError_t e = y3::launch_x2_to_f32(net->tdev[t], dst_dev, (size_t)batch * sp * sp, net->tensors[t].channels, (hipStream_t)stream);
         if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_read_tensor: %s", hipGetErrorString(e));
@@ -1339,11 +1418,12 @@ y3_status y3_net_read_tensor(y3_net *net, int t, int batch, float *dst_dev, size
     HIP_TRY(hipMemcpyAsync(dst_dev, net->tdev[t], n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return Y3_OK;
 }
+Y3_CATCH("y3_net_read_tensor")
 
 // ------------------------------------------------------------------------------------------ image input
 y3_status y3_preprocess_image(const void *image_dev, int is_uint8, int height, int width, int channels,
                               float *batch_dev, int slot, int image_size, void *stream)
-{
+try {
     if (!image_dev || !batch_dev || height <= 0 || width <= 0 || channels < 3 || channels > 4 || slot < 0 ||
         image_size <= 0 || is_uint8 < 0 || is_uint8 > 2 || (is_uint8 == 0 && ((uintptr_t)image_dev & 3)))
         return fail(Y3_ERR_INVALID, "y3_preprocess_image: bad argument (channels must be 3 or 4)");
@@ -1352,6 +1432,7 @@ y3_status y3_preprocess_image(const void *image_dev, int is_uint8, int height, i
     if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_preprocess_image launch: %s", hipGetErrorString(e));
     return Y3_OK;
 }
+Y3_CATCH("y3_preprocess_image")
 
 // ------------------------------------------------------------------------------------------ TFRecord checksum
 uint32_t y3_crc32c(const void *data_host, size_t nbytes)
@@ -1416,24 +1497,26 @@ static y3_status decode_common(const float *const grids[3], const int32_t gs[3],
 
 y3_status y3_yolo_decode(const float *const grids_dev[3], const int32_t grid_sizes[3], int batch, int nclasses,
                          const float *anchors_host, float *bboxes_dev, float *conf_dev, float *probs_dev, void *stream)
-{
+try {
     if (!conf_dev || !probs_dev) return fail(Y3_ERR_INVALID, "y3_yolo_decode: null output");
     return decode_common(grids_dev, grid_sizes, batch, nclasses, anchors_host, bboxes_dev, conf_dev, probs_dev, nullptr,
                          nullptr, stream, "y3_yolo_decode");
 }
+Y3_CATCH("y3_yolo_decode")
 
 y3_status y3_yolo_decode_scores(const float *const grids_dev[3], const int32_t grid_sizes[3], int batch, int nclasses,
                                 const float *anchors_host, float *bboxes_dev, int64_t *class_idx_dev,
                                 float *scores_dev, void *stream)
-{
+try {
     if (!class_idx_dev || !scores_dev) return fail(Y3_ERR_INVALID, "y3_yolo_decode_scores: null output");
     return decode_common(grids_dev, grid_sizes, batch, nclasses, anchors_host, bboxes_dev, nullptr, nullptr,
                          class_idx_dev, scores_dev, stream, "y3_yolo_decode_scores");
 }
+Y3_CATCH("y3_yolo_decode_scores")
 
 y3_status y3_class_scores(const float *conf_dev, const float *probs_dev, int batch, int n, int nclasses,
                           int64_t *class_idx_dev, float *scores_dev, void *stream)
-{
+try {
     if (!conf_dev || !probs_dev || !class_idx_dev || !scores_dev || batch <= 0 || n <= 0 || nclasses <= 0)
         return fail(Y3_ERR_INVALID, "y3_class_scores: bad argument");
     hipError_t e = y3::launch_class_scores(conf_dev, probs_dev, (size_t)batch * n, nclasses, class_idx_dev, scores_dev,
@@ -1441,6 +1524,7 @@ y3_status y3_class_scores(const float *conf_dev, const float *probs_dev, int bat
     if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_class_scores launch: %s", hipGetErrorString(e));
     return Y3_OK;
 }
+Y3_CATCH("y3_class_scores")
 
 // ------------------------------------------------------------------------------------------ forward + decode
 namespace {
@@ -1464,8 +1548,12 @@ bool heads_can_decode(const y3_net *net)
                 return false;
         }
         if (producers != 1) return false;
+        // the fused route does not write the grid: nobody inside the net may read it (fp32 plans never stage an output, so a
+        // consumer would read the caller's buffer -- on this route uninitialised scratch)
+        for (const ConvSlot &c : net->convs)
+            if (c.d.src0 == t || c.d.src1 == t || c.d.residual == t) return false;
         for (const y3_aux_desc &x : net->aux)
-            if (x.dst == t) return false;
+            if (x.dst == t || x.src0 == t || x.src1 == t) return false;
     }
     return true;
 }
@@ -1473,7 +1561,7 @@ bool heads_can_decode(const y3_net *net)
 
 y3_status y3_net_forward_decode(y3_net *net, const float *images_dev, int batch, const float *anchors_host, float *bboxes_dev,
                                 int64_t *class_idx_dev, float *scores_dev, void *stream)
-{
+try {
     if (!net || !images_dev || !anchors_host || !bboxes_dev || !class_idx_dev || !scores_dev || batch <= 0)
         return fail(Y3_ERR_INVALID, "y3_net_forward_decode: bad argument");
     if (net->nclasses <= 0) return fail(Y3_ERR_STATE, "y3_net_forward_decode: the net was created without detection heads (nclasses = 0)");
@@ -1514,13 +1602,14 @@ y3_status y3_net_forward_decode(y3_net *net, const float *images_dev, int batch,
     net->fuse = nullptr;
     return st;
 }
+Y3_CATCH("y3_net_forward_decode")
 
 // ------------------------------------------------------------------------------------------ nms
 // ------------------------------------------------------------------------------------------ whole pipeline
 y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const float *anchors_host, int max_boxes,
                         float iou_threshold, float score_threshold, void *packed_dev, int32_t *num_valid_dev,
                         void *stream)
-{
+try {
     if (!net || !images_dev || !anchors_host || !packed_dev || !num_valid_dev || batch <= 0)
         return fail(Y3_ERR_INVALID, "y3_net_detect: bad argument");
     if (net->nclasses <= 0) return fail(Y3_ERR_STATE, "y3_net_detect: the net was created without detection heads (nclasses = 0)");
@@ -1549,13 +1638,14 @@ y3_status y3_net_detect(y3_net *net, const float *images_dev, int batch, const f
     if (st != Y3_OK) return st;
     return y3_pack_detections(boxes, cls, scores, sel, num_valid_dev, batch, (int)n, max_boxes, packed_dev, stream);
 }
+Y3_CATCH("y3_net_detect")
 
 size_t y3_nms_workspace_bytes(int batch, int n) { return (batch > 0 && n > 0) ? y3::nms_workspace_bytes(batch, n) : 0; }
 
 y3_status y3_nms_padded(const float *bboxes_dev, const float *scores_dev, int batch, int n, int max_output_size,
                         float iou_threshold, float score_threshold, int32_t *selected_idx_dev,
                         int32_t *num_valid_dev, void *workspace_dev, size_t workspace_bytes, void *stream)
-{
+try {
     if (!bboxes_dev || !scores_dev || !selected_idx_dev || !num_valid_dev || batch <= 0 || n <= 0)
         return fail(Y3_ERR_INVALID, "y3_nms_padded: bad argument");
     if (max_output_size <= 0 || max_output_size > 1024)
@@ -1570,11 +1660,12 @@ y3_status y3_nms_padded(const float *bboxes_dev, const float *scores_dev, int ba
     if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_nms_padded launch: %s", hipGetErrorString(e));
     return Y3_OK;
 }
+Y3_CATCH("y3_nms_padded")
 
 y3_status y3_pack_detections(const float *bboxes_dev, const int64_t *class_idx_dev, const float *scores_dev,
                              const int32_t *selected_idx_dev, const int32_t *num_valid_dev, int batch, int n,
                              int max_out, void *packed_dev, void *stream)
-{
+try {
     if (!bboxes_dev || !class_idx_dev || !scores_dev || !selected_idx_dev || !num_valid_dev || !packed_dev ||
         batch <= 0 || n <= 0 || max_out <= 0)
         return fail(Y3_ERR_INVALID, "y3_pack_detections: bad argument");
@@ -1583,5 +1674,6 @@ y3_status y3_pack_detections(const float *bboxes_dev, const int64_t *class_idx_d
     if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_pack_detections launch: %s", hipGetErrorString(e));
     return Y3_OK;
 }
+Y3_CATCH("y3_pack_detections")
 
 }  // extern "C"

@@ -38,16 +38,19 @@ struct ConvArgs {
     // measurement only (y3_net_measure_sclk): when non-null, thread 0 of the middle workgroup stores {s_memtime, s_memrealtime}
     // at its entry and after its epilogue -> the shader clock held while that workgroup ran.  Null in every product launch.
     unsigned long long *clk_stamps;   // [4]
+    int n_cus;             // compute units of the net's device, read once by y3_net_plan: sizes the grids of the persistent kernels (conv_res_*.hip)
+    int device;            // the net's device index (the launch goes there: Y3_ENTER_DEVICE); -1 = not known, launchers ask the runtime
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to the
 // device's copy of the code object, so a process driving several GPUs must set it on each.
 struct LdsAttrOnce { unsigned long long done = 0; };   // bit d: set on device d (d < 64)
-inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes)
+// `dev`: the device the launch goes to, when the caller knows it (ConvArgs::device, set from the net at plan time) -- then a launch
+// makes no runtime call here at all once the attribute is set; -1: ask the runtime (stand-alone launches outside a net).
+inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes, int dev = -1)
 {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (dev < 0 && (e = hipGetDevice(&dev)) != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && ((st.done >> dev) & 1ull)) return hipSuccess;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess && dev >= 0 && dev < 64) st.done |= 1ull << dev;
@@ -55,7 +58,7 @@ inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes)
 }
 
 // tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
-static constexpr int TILE_COUNT = 34;  // 20..22, 25: retired ids (the timing-only probes of rounds 1-2); 33: the weight-resident 3x3 kernel (conv_res_f32.hip)
+static constexpr int TILE_COUNT = 35;  // 20..22, 25: retired ids (the timing-only probes of rounds 1-2); 33: the weight-resident 3x3 kernel (conv_res_f32.hip)
 struct TileInfo { int bm, bn, waves, stages; };
 TileInfo conv_tile_info(int tile);
 bool conv_tile_built(int tile);        // false: retired id
@@ -96,24 +99,20 @@ struct StemArgs {
     // kernel entry and exit -> shader clock held during the kernel = d(memtime) / d(memrealtime) x 100 MHz.  Null in
     // every product launch: no stamp instruction executes then.
     unsigned long long *clk_stamps;  // [4]
+    int device;            // as ConvArgs::device
+    int n_cus;             // as ConvArgs::n_cus (one / two persistent workgroups per CU)
 };
 hipError_t launch_conv_stem_f32(const StemArgs &a, hipStream_t s);
 hipError_t launch_conv_stem_bf16(const StemArgs &a, hipStream_t s);   // conv0 on bf16 MFMA from split (hi + lo) operands (~2^-16 per product), bf16 patch, conv1 on bf16 MFMA
 
 // bf16 path (conv_bf16.hip); TileInfo.stages holds BK for these tiles
-static constexpr int BF16_TILE_COUNT = 37;   // 32: the weight-resident 3x3 kernel (conv_res_bf16.hip); 33..35: tap-row reuse (conv_bf16_rs.hip)
+static constexpr int BF16_TILE_COUNT = 37;   // 32: the weight-resident 3x3 kernel (conv_res_bf16.hip); 20, 33..36: retired ids
 TileInfo conv_bf16_tile_info(int tile);
 bool conv_bf16_tile_built(int tile);
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);
 // weight-resident 3x3 / stride-1 conv for Cin = 32 / 64 (conv_res_bf16.hip): the early short-K layers of the bf16 path
 bool conv_res_bf16_fits(const ConvArgs &a);
 hipError_t launch_conv_res_bf16(const ConvArgs &a, hipStream_t s);
-// 3x3 / stride-1 conv with the activation tile fetched once per kernel ROW and reused for its three taps (conv_bf16_rs.hip): Cin % 128 == 0
-bool conv_bf16_rs_fits(const ConvArgs &a);
-hipError_t launch_conv_bf16_rs(const ConvArgs &a, int tile, hipStream_t s);
-// 256 x 256 block tile on four waves of 128 x 128 (one per SIMD), software-pipelined fragment reads (conv_bf16_w4.hip): bf16 tile id 36
-bool conv_bf16_w4_fits(const ConvArgs &a);
-hipError_t launch_conv_bf16_w4(const ConvArgs &a, hipStream_t s);
 hipError_t launch_conv_first_bf16(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void *x, float *y, size_t n, hipStream_t s);
 
