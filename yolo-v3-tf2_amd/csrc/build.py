@@ -22,14 +22,14 @@ def build(force=False, verbose=False, defines=(), out=None, only=None):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".h", ".hip", ".cpp"))]
-    deps.append(os.path.join(HERE, "..", "..", "include", "y3.h"))
-    newest = max(os.path.getmtime(d) for d in deps)
+    # an object is stale when its own source or any header is newer (no source includes another source)
+    headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")] + [os.path.join(HERE, "..", "..", "include", "y3.h")]
+    newest_header = max(os.path.getmtime(d) for d in headers)
     objs, jobs = [], []
     for src in SOURCES:
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_header, os.path.getmtime(os.path.join(HERE, src))):
             cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
