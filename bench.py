@@ -365,25 +365,13 @@ def main():
 
     last = {}
 
-    # --graph: the whole step is ONE C call (y3_net_detect: every lane runs NMS + pack for its own images behind its last conv, so one lane's NMS
-    # overlaps the other's conv tail) -- bit-identical to the composed calls (tests/test_gpu_parity.py::test_detect_single_call_equals_composed_pipeline);
-    # eager runs keep the composed calls so that the conv-stack events sit inside the timed region
-    one_call = bool(args.graph)
-
     def step(i=None):
-        if one_call and i is None:
-            packed, nv = net.detect(images, anchors, M, 0.5, 0.1)
-            if comm is not None:
-                return comm.allgather(packed, nv, out=gathered)
-            if use_dist:
-                return gather_torch(packed, nv)
-            return allgather_detections(packed, nv, out=gathered)
-        if i is not None and i >= 0:
+        if i is not None:
             ev[i][0].record()
         # conv program with the head convs decoding their own tiles (y3_net_forward_decode: the grids are neither written nor read
         # back); the events bracket it, so roofline.achieved counts the conv FLOPs against conv stack + fused decode
         bboxes, cls, scores = net.forward_decode(images, anchors)
-        if i is not None and i >= 0:
+        if i is not None:
             ev[i][1].record()
         sel, nv = runtime.nms_padded(bboxes, scores, M, 0.5, 0.1)
         packed = runtime.pack_detections(bboxes, cls, scores, sel, nv)
@@ -405,8 +393,6 @@ def main():
     # match the oracle; fp32-accurate modes only (bf16 is measured against its own bar in tests/)
     parity = None
     fused_equal = None
-    if one_call:     # the gate below looks at the decoded tensors: one composed pass for it
-        step(-1)
     if rank == 0 and args.parity_images > 0:
         # the route the loop times (y3_net_forward_decode: the head convs decode their own tiles) against the composed route
         # (forward into grids + y3_yolo_decode_scores) on this very plan and batch: bit-identical by contract, checked here at the

@@ -149,13 +149,6 @@ y3_status y3_net_keep_activations(y3_net *net, int keep);
  * bf16 where the pipeline stores it; against the one-launch-per-conv form a fraction of a percent of conv0's bf16 values round
  * the other way (bounded by tests/test_gpu_parity.py::test_fused_stem_bf16_matches_oracle_and_the_two_launch_form). */
 y3_status y3_net_set_stem_fusion(y3_net *net, int on);
-/* bf16 plans.  1 (default): a 1x1 / stride-1 conv 256 -> 128 whose only input is the output of the conv right before it, that conv having
- * exactly 256 output channels -- a residual block's bottleneck conv behind the previous block's 3x3, reference config/models/yolov3/backbone.yaml
- * (the eight blocks at 52 x 52) and neck2.yaml, core/parse_model.py:27-52 -- runs INSIDE the producing conv's launch whenever that launch takes the
- * 256x256 tile: computed from the output tile while it is still in LDS (pointwise: no halo), both tensors written.  Its own launch, its read of the
- * 256-channel tensor and its prologue / epilogue disappear.  Bit-identical to the two-launch form with the 1x1 on a 16x16x32 tile (same products,
- * same k order; tests/test_gpu_parity.py::test_bf16_fused_1x1_tail_bit_identical_to_two_launches).  0: one launch per conv. */
-y3_status y3_net_set_tail_fusion(y3_net *net, int on);
 /* Measurement aid (bench.py): the shader clock the chip holds under this network's load.  Runs `forwards` forwards back to
  * back (grids_dev as for y3_net_forward); in the last one, thread 0 of the middle workgroup of the conv with the most FLOPs (fp32
  * plans: an MFMA conv launch; bf16 plans: the fused stem kernel) reads s_memtime and s_memrealtime at its entry and after

@@ -516,74 +516,6 @@ def test_bf16_weight_resident_3x3_matches_oracle_and_generic_tiles(rt, cin, cout
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("cin,S,B,stride", [(128, 13, 5, 1), (64, 20, 2, 1), (128, 26, 3, 2), (256, 9, 7, 1), (128, 52, 1, 1)])
-def test_bf16_fused_1x1_tail_bit_identical_to_two_launches(rt, cin, S, B, stride):
-    """csrc/conv_bf16.hip TAIL (y3_net_set_tail_fusion, default on): a 1x1 conv 256 -> 128 that reads the output of a 256-channel conv runs inside
-    that conv's launch (256x256 tile: the output tile goes to LDS, 64 more MFMAs per wave contract it with the 1x1's weights, both tensors are
-    stored).  Against the two-launch form -- the same producer tile, the 1x1 on a 16x16x32 tile of its own (same products, same k order) -- every
-    tensor of the chain must be EQUAL bit for bit: a 3x3 / 1 and a 3x3 / 2 producer, with and without a shortcut, BN + leaky and BN + linear tails, pixel
-    counts that leave a ragged last tile (845, 800, 507, 567 pixels) and tiles that cross images; the 1x1 head that follows the last 256-channel conv
-    writes an fp32 net output and must NOT be fused.  The fused net reports the tail convs with 0 ms (they have no launch), the other one does not."""
-    from tests.helpers import mini_program
-    from yolo_v3_tf2_amd.weights import synthetic_weights
-    from yolo_v3_tf2_amd import _lib
-    from oracle import oracle as O
-    chain = [dict(filters=256, size=3, stride=stride), dict(filters=128, size=1), dict(filters=256, size=3, shortcut=-3),
-             dict(filters=128, size=1, act="linear"), dict(filters=256, size=3, bn=False, act="linear")]
-    heads = [dict(filters=128, size=1), dict(filters=64, size=1), dict(filters=128, size=1, bn=False, act="linear")]
-    p = mini_program(cin, chain, heads)
-    w = synthetic_weights(p, seed=55)
-    x = np.random.default_rng(55).standard_normal((B, S, S, cin)).astype(np.float32)
-    ops = p.conv_ops()
-    probe = [o.dst for o in ops[:5]]
-    tails = [i for i, o in enumerate(ops[:5]) if o.size == 1]
-    assert tails == [1, 3]
-    ref, kept = O.forward(p, w, x, bf16=True, keep=set(probe))
-    xin = _cuda(O.round_bf16(x)).to(torch.bfloat16)
-    outs, mids, ms = {}, {}, {}
-    for name in ("fused", "two"):
-        net = rt.Net(p)
-        net.load_weights(w)
-        net.keep_activations(True)
-        if name == "two":
-            net.set_tail_fusion(0)
-        for slot, o in enumerate(net.conv_ops):
-            if o.cout == 256:
-                net.set_tile_bf16(slot, 24)
-            elif slot in tails:
-                net.set_tile_bf16(slot, 27)          # what runs when the tail is not fused: a 16x16x32 tile
-        net.plan(B, S, _lib.Y3_DTYPE_BF16)
-        net.set_lanes(1)
-        outs[name] = [g.clone() for g in net.forward(xin)]
-        mids[name] = [net.read_tensor(t, B).clone() for t in probe]
-        again = net.forward(xin)
-        torch.cuda.synchronize()
-        assert all(torch.equal(a, b) for a, b in zip(outs[name], again))
-        ms[name] = net.profile_convs(xin)
-        for r, g in zip(ref, outs[name]):
-            g = g.cpu().numpy().reshape(r.shape)
-            assert np.abs(g - r).max() <= 4e-3 * max(1.0, float(np.abs(r).max())), (name, float(np.abs(g - r).max()))
-    assert all(ms["fused"][i] == 0.0 for i in tails) and all(ms["two"][i] > 0.0 for i in tails), (ms["fused"][:5], ms["two"][:5])
-    assert all(ms["fused"][i] > 0.0 for i in range(5, 8))     # the head 1x1 behind the last 256-channel conv has its own launch
-    # the first producer reads the input itself: every element within its own bf16 ulp of the oracle's
-    g0 = mids["fused"][0].float().cpu().numpy()
-    d = np.abs(g0 - kept[probe[0]])
-    assert (d <= _bf16_ulp_elem(g0, kept[probe[0]]) + 1e-5 * float(np.abs(kept[probe[0]]).max())).all()
-    for k, (a, b) in enumerate(zip(mids["fused"] + outs["fused"], mids["two"] + outs["two"])):
-        assert torch.equal(a, b), k
-    # ... and with the arena's buffer reuse on (no keep_activations): the tail's output is live from the producer's op on -- the planner must not
-    # hand it the block of the producer's own input (the previous bottleneck tensor: same size, dead one op later)
-    net = rt.Net(p)
-    net.load_weights(w)
-    for slot, o in enumerate(net.conv_ops):
-        if o.cout == 256:
-            net.set_tile_bf16(slot, 24)
-    net.plan(B, S, _lib.Y3_DTYPE_BF16)
-    for _ in range(2):
-        for a, b in zip(net.forward(xin), outs["two"]):
-            assert torch.equal(a, b)
-
-
 def test_bf16_intermediate_tensors_within_one_ulp(rt, program, weights):
     """Intermediate bf16 activations (after residual adds / the fused upsample+concat conv) vs the bf16 oracle."""
     from yolo_v3_tf2_amd import _lib
@@ -867,10 +799,8 @@ def test_early_chunk_bit_identical(rt, program, weights, mode):
 
 @pytest.mark.parametrize("B,lanes", [(3, 1), (5, 2), (7, 3)])
 def test_detect_single_call_equals_composed_pipeline(rt, program, weights, anchors, B, lanes):
-    """y3_net_detect (forward -> decode/score -> NMS -> pack on net-owned scratch) == the four calls made one by one.  With sub-batch lanes every
-    lane runs NMS + pack for its own images on its own stream behind its last conv (round 5): the same kernels on a sub-batch, the batch's box [0,0]
-    handed to every launch -- selections, counts and packed rows must equal the batch-wide launches bit for bit, ragged lane sizes (5 = 2 + 3,
-    7 = 2 + 2 + 3) included, on a second call (scratch reused), and replayed from a captured graph."""
+    """y3_net_detect (forward -> decode/score -> NMS -> pack on net-owned scratch) == the four calls made one by one: with one, two and three
+    sub-batch lanes (ragged lane sizes 5 = 2 + 3, 7 = 2 + 2 + 3), on a second call (scratch reused), and replayed from a captured graph."""
     x = _cuda(np.random.default_rng(31).random((B, 128, 128, 3), dtype=np.float32))
     net = rt.Net(program)
     net.load_weights(weights)
@@ -889,7 +819,7 @@ def test_detect_single_call_equals_composed_pipeline(rt, program, weights, ancho
     assert torch.equal(idx[0, :n0], sel[0, :n0]) and torch.equal(boxes[0, :n0], bb[0][sel[0, :n0].long()])
     with pytest.raises(rt.Y3Error):
         net.detect(x, anchors, 0, 0.5, 0.05)
-    # the same call captured into a HIP graph (lane streams, the cross-lane event and the per-lane NMS inside the capture) and replayed
+    # the same call captured into a HIP graph (the lanes' forked streams inside the capture) and replayed
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

@@ -58,9 +58,10 @@ def main():
     for _ in range(a.reps):
         net.forward(x)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (8 * cap))()
-    assert getattr(lib, cpy)(buf, C.c_int(8 * cap)) == 0
-    st_all = np.frombuffer(buf, dtype=np.uint64).reshape(cap, 8).astype(np.int64)
+    W = 8                                             # words per workgroup record
+    buf = (C.c_ulonglong * (W * cap))()
+    assert getattr(lib, cpy)(buf, C.c_int(W * cap)) == 0
+    st_all = np.frombuffer(buf, dtype=np.uint64).reshape(cap, W).astype(np.int64)
     n = int((st_all[:, 0] > 0).sum())                 # stamped workgroups (blockIdx order: a prefix)
     nwg = n
     st = st_all[:n]

@@ -41,16 +41,6 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 // Same LDS image, same bytes read per K tile, same MFMA cycles per FLOP; the chip holds a higher clock on this shape
 // (MI355X_MICROARCH.md "DVFS give-back" item 7: 1.12-1.15 x the FLOP/s on random data).  Fragment: lane l holds k = 8 (l >> 4) ..
 // + 7 of row l & 15; C: acc[mb][nb][j] = row 16 mb + 4 (l >> 4) + j, column 16 nb + (l & 15).
-// SWAP (round 5): the MFMA is issued with its operands exchanged -- D' = W x X^T, rows = output channels, columns = pixels -- so that a lane
-// ends the K loop holding 4 CONSECUTIVE CHANNELS of one pixel per accumulator block instead of 4 consecutive pixels of one channel, and the
-// weight rows are dealt to the LDS rows in an order (at the DMA source address: free) that makes the lane's blocks adjoin: lane (g = l >> 4,
-// c = l & 15) owns channels [8 g, 8 g + 8) and [32 + 8 g, 32 + 8 g + 8) of the wave's 64 for pixel c of every pixel block -- whole 16-byte
-// pieces of bf16 output, finished per lane.  Same products, same k order inside the MFMA: bit-identical (digests equal over the whole network,
-// profiles/r05_ab_bf16_swap_epilogue.txt).  As the epilogue of the stand-alone tiles it LOST (-2.8 % on the step: a pass of 16 lanes then stores
-// 16 bytes to each of 16 lines instead of two full lines) and is not used there.  It is the layout of the TAIL variant below, whose output tile
-// is assembled in LDS as the A operand of a second GEMM and leaves through coalesced stores from there.
-// TAIL (round 5; the 256x256 tile with 256 = all output channels): the 1x1 conv that reads this launch's output -- a residual block's
-// 256 -> 128 bottleneck -- runs in the same launch: pieces -> T[256 px][256 ch] in LDS -> 64 more MFMAs per wave -> both tensors stored.
 #ifdef Y3_PHASE_STAMPS
 // Diagnostic build only (csrc/build.py --variant ... -DY3_PHASE_STAMPS, tools/phase_stamps.py): thread 0 of every workgroup of the
 // launches whose K equals y3_dbg_sel_k stores s_memrealtime (100 MHz) at kernel entry, before the first fetch, after the first
@@ -62,10 +52,9 @@ __device__ int y3_dbg_sel_k = -1;
 #define Y3_STAMP(k) do { } while (0)
 #endif
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false, int MINW = 1, bool M16 = false, bool TAIL = false>
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false, int MINW = 1, bool M16 = false>
 __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvArgs p)
 {
-    static_assert(!TAIL || (M16 && !OUT_F32 && !CONCAT && TM == 2 && TN == 2 && WR == 4 && WC == 4 && BK == 64), "the fused 1x1 tail is built on the 256x256 16-wave tile");
     Y3_STAMP(0);
 #ifdef Y3_PHASE_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 8192 && p.K == y3_dbg_sel_k) {
@@ -76,7 +65,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
     static_assert(!DMA || BK == 64 || BK == 32, "LDS-DMA variant needs 128-byte or 64-byte rows");
     static_assert(!M16 || (DMA && BK == 64), "the 16x16x32 form is built on the 128-byte swizzled rows");
     constexpr int MB = M16 ? 2 * TM : TM, NB = M16 ? 2 * TN : TN;   // accumulator blocks per wave
-    constexpr bool SWAP = TAIL;                                     // channel-major accumulators (file header): only where the tile goes through LDS anyway
     using acc_t = typename std::conditional<M16, f32x4, f32x16>::type;
     constexpr int DROWS = 1024 / (2 * BK);   // rows one wave DMA instruction (1 KiB) fills: 8 (BK 64) or 16 (BK 32)
     constexpr int BM = 32 * TM * WR;
@@ -149,14 +137,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
     }
     unsigned boff[BP];
 #pragma unroll
-    for (int j = 0; j < BP; ++j) {
-        int row = j * RP + lrow;            // LDS row of the weight tile this lane fills in pass j ...
-        if constexpr (SWAP) {               // ... and the weight row (output channel) it holds: block jb, row r of a wave's 32 TN rows <-> channel
-            const int wl = row % (32 * TN), jb = wl >> 4, r = wl & 15;                       // 32 (jb >> 1) + 8 (r >> 2) + 4 (jb & 1) + (r & 3)
-            row = row - wl + 32 * (jb >> 1) + 8 * (r >> 2) + 4 * (jb & 1) + (r & 3);
-        }
-        boff[j] = (unsigned)((n0 + row) * p.K + lchunk) * 2u;
-    }
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)((n0 + j * RP + lrow) * p.K + lchunk) * 2u;
 
     int tap = 0, c0 = 0;
     unsigned avoff[AP];
@@ -248,34 +229,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
             for (int e = 0; e < (M16 ? 4 : 16); ++e) acc[i][j][e] = 0.0f;
 
     const int KT = p.K / BK;
-    // SWAP: the tile's BN scale / shift values into LDS behind the operand stages (visible after the barrier below).  The epilogue reads
-    // them with ds_read_b128 -- LDS operations count on lgkmcnt, so nothing in the epilogue waits on the vector-memory queue after the
-    // shortcut loads (vector-memory operations retire in issue order: a global load issued behind the tile's first stores returns only
-    // when those stores have been acknowledged -- profiles/r05_ab_bf16_swap_epilogue.txt: +4 us per tile that way)
-    // TAIL (the 256x256 tile only; n0 = 0): LDS map = [0, 128 KB) operand stages, later the output tile T; [128 KB, 144 KB) the tail conv's
-    // weights for k = 0..63 ([128 rows][128 B], filled by LDS-DMA right here); then scale / shift of the tile and of the tail conv (3 KB)
-    constexpr int TAIL_W_BYTES = TAIL ? 128 * 128 : 0;
-    float *const s_scale = reinterpret_cast<float *>(smem + 2 * STAGE_B + TAIL_W_BYTES);
-    if constexpr (SWAP) {
-        if (tid < BN / 4) {
-            *reinterpret_cast<f32x4 *>(s_scale + 4 * tid) = *reinterpret_cast<const f32x4 *>(p.scale + n0 + 4 * tid);
-            *reinterpret_cast<f32x4 *>(s_scale + BN + 4 * tid) = *reinterpret_cast<const f32x4 *>(p.shift + n0 + 4 * tid);
-        }
-    }
-    if constexpr (TAIL) {
-        if (tid < 32) {
-            *reinterpret_cast<f32x4 *>(s_scale + 2 * BN + 4 * tid) = *reinterpret_cast<const f32x4 *>(p.tail.scale + 4 * tid);
-            *reinterpret_cast<f32x4 *>(s_scale + 2 * BN + 128 + 4 * tid) = *reinterpret_cast<const f32x4 *>(p.tail.shift + 4 * tid);
-        }
-        // tail weights, k chunk 0: wave w fills LDS rows [8 w, 8 w + 8) (one 1-KiB instruction); LDS row l of a wave column's 32 rows holds
-        // output channel 8 (r >> 2) + 4 jb + (r & 3) (l = 16 jb + r): the channel-major accumulator layout of the tail's own epilogue
-        const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.tail.w), 0, 128u * 256u * 2u, 0x00020000);
-        const int l = wave * 8 + (lane >> 3), wl = l & 31, jb = wl >> 4, r = wl & 15;
-        const int ch = l - wl + 8 * (r >> 2) + 4 * jb + (r & 3);
-        const int lc = (lane & 7) ^ ((l >> 1) & 7);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rst, (__attribute__((address_space(3))) void *)(smem + 2 * STAGE_B + wave * 1024), 16,
-                                                 (ch * 256 + lc * 8) * 2, 0, 0, 0);
-    }
     Y3_STAMP(1);
     if (DMA) {
         fetch_dma(0);
@@ -316,8 +269,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                    else if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -333,127 +285,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
     // ---- epilogue through LDS, one 32-row sub-tile of every wave per pass ----------------------------------
     // pass i: wave (wr, wc) writes rows [wr*32, +32) x cols [wc*32*TN, +32*TN) of a [WR*32][BN+4] fp32 tile (its i-th
     // accumulator row block), then all threads convert 8 consecutive channels each and store 16 B.
-    if constexpr (SWAP) {
-        // ---- bf16 output, channel-major accumulators: every lane finishes its own 8-channel pieces (file header) -----------------
-        // lane (g = fh, c = fr): pixel c of pixel block i; channels nw + 32 hb + 8 g + [0, 8) from blocks 2 hb (first four) and 2 hb + 1
-        unsigned short *dstb = static_cast<unsigned short *>(p.dst);
-        const unsigned short *res = static_cast<const unsigned short *>(p.residual);
-        const int nw = n0 + wc * 32 * TN;
-        const int mw = m0 + wr * 32 * TM + fr;      // this lane's pixel in block 0; block i: + 16 i
-        u32x4 rr[TN][MB];
-        if (res) {   // the whole wave tile's shortcut operand first (TN x MB pieces per lane): one round trip for all of it
-#pragma unroll
-            for (int hb = 0; hb < TN; ++hb)
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-                    rr[hb][i] = (mw + 16 * i < p.M) ? *reinterpret_cast<const u32x4 *>(res + (size_t)(mw + 16 * i) * p.Cout + nw + 32 * hb + 8 * fh)
-                                                    : u32x4{0u, 0u, 0u, 0u};
-        }
-        // channel half outermost: its 16 scale / shift values live only while its MB pixel blocks are finished (128-register budget of the
-        // 16-wave tiles: 64 accumulators + the shortcut pieces + both halves' constants would spill)
-#pragma unroll
-        for (int hb = 0; hb < TN; ++hb) {
-            f32x4 sc[2], sh[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                sc[q] = *reinterpret_cast<const f32x4 *>(s_scale + wc * 32 * TN + 32 * hb + 8 * fh + 4 * q);
-                sh[q] = *reinterpret_cast<const f32x4 *>(s_scale + BN + wc * 32 * TN + 32 * hb + 8 * fh + 4 * q);
-            }
-#pragma unroll
-            for (int i = 0; i < MB; ++i) {
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    v[k] = acc[i][2 * hb + (k >> 2)][k & 3] * sc[k >> 2][k & 3] + sh[k >> 2][k & 3];
-                    if (p.leaky) v[k] = fmaxf(v[k], 0.1f * v[k]);
-                }
-                if (res) {   // shortcut added in fp32 before the single rounding to bf16 (the oracle's bf16 mode rounds where the pipeline stores)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        v[2 * k] = __uint_as_float(rr[hb][i][k] << 16) + v[2 * k];
-                        v[2 * k + 1] = __uint_as_float(rr[hb][i][k] & 0xffff0000u) + v[2 * k + 1];
-                    }
-                }
-                u32x4 out;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) out[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
-                if constexpr (TAIL) {
-                    // into the output tile T[256 pixels][256 channels] bf16 in LDS (rows of 512 B, 16-byte chunk L of pixel row R at L ^ (R & 15)):
-                    // the A operand of the tail GEMM and, afterwards, the source of this lane's own global stores
-                    *reinterpret_cast<u32x4 *>(smem + (wr * 64 + 16 * i + fr) * 512 + (((wc * 8 + 4 * hb + fh) ^ fr) << 4)) = out;
-                } else {
-                    if (mw + 16 * i < p.M) *reinterpret_cast<u32x4 *>(dstb + (size_t)(mw + 16 * i) * p.Cout + nw + 32 * hb + 8 * fh) = out;
-                }
-            }
-        }
-        if constexpr (TAIL) {
-            // ---- the 1x1 conv that reads this tile (p.tail): out2[256 px][128] = T[256][256] x W1^T, wave (wr, wc) = 64 pixels x 32 channels -------
-            // k order 0..255 in steps of 32 on one accumulator chain per block = the stand-alone launch's (16x16x32 tiles): bit-identical.
-            // W1: k < 64 from LDS (prefetched at kernel start), k >= 64 from registers, requested now -- no store has been issued yet, so these
-            // loads wait for nothing but the shortcut loads in front of them
-            const unsigned short *w1 = static_cast<const unsigned short *>(p.tail.w);
-            bf16x8 w1r[2][6];
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {
-                const unsigned short *row = w1 + (size_t)(wc * 32 + 8 * (fr >> 2) + 4 * jb + (fr & 3)) * 256 + 8 * fh;
-#pragma unroll
-                for (int t = 0; t < 6; ++t) w1r[jb][t] = *reinterpret_cast<const bf16x8 *>(row + 64 + 32 * t);
-            }
-            // T complete (this wave's LDS writes done, then the barrier).  Raw: __syncthreads() would also drain the weight loads just issued
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            f32x4 acc2[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb) acc2[i][jb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            const unsigned char *ta = smem + (wr * 64 + fr) * 512;                 // this lane's pixel row of block 0; block i: + 16 rows
-            const unsigned char *tb = smem + 2 * STAGE_B + (wc * 32 + fr) * 128;    // W1 chunk 0: LDS row of block 0; block 1: + 16 rows
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {   // k step t: channels [32 t, 32 t + 32); this lane's 16-byte piece = chunk 4 t + fh of the pixel row
-                bf16x8 fa2[4], fb2[2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa2[i] = *reinterpret_cast<const bf16x8 *>(ta + i * 16 * 512 + (((4 * t + fh) ^ fr) << 4));
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb) {
-                    if (t < 2) fb2[jb] = *reinterpret_cast<const bf16x8 *>(tb + jb * 16 * 128 + (((4 * t + fh) ^ ((fr >> 1) & 7)) << 4));
-                    else fb2[jb] = w1r[jb][t - 2];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jb = 0; jb < 2; ++jb) acc2[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb2[jb], fa2[i], acc2[i][jb], 0, 0, 0);
-            }
-            // ---- stores: the 3x3's tile out of T, coalesced (32 consecutive lanes = one pixel's 512 bytes), then the tail's 64 pixels x 8 channels ----
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int q = tid + it * NT, row = q >> 5, pc = q & 31;
-                const u32x4 o = *reinterpret_cast<const u32x4 *>(smem + row * 512 + ((pc ^ (row & 15)) << 4));
-                if (m0 + row < p.M) *reinterpret_cast<u32x4 *>(dstb + (size_t)(m0 + row) * 256 + pc * 8) = o;
-            }
-            unsigned short *dst2 = static_cast<unsigned short *>(p.tail.dst);
-            const float *s2 = s_scale + 2 * BN;
-            const f32x4 sc2a = *reinterpret_cast<const f32x4 *>(s2 + wc * 32 + 8 * fh), sc2b = *reinterpret_cast<const f32x4 *>(s2 + wc * 32 + 8 * fh + 4);
-            const f32x4 sh2a = *reinterpret_cast<const f32x4 *>(s2 + 128 + wc * 32 + 8 * fh), sh2b = *reinterpret_cast<const f32x4 *>(s2 + 128 + wc * 32 + 8 * fh + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[k] = acc2[i][0][k] * sc2a[k] + sh2a[k];
-                    v[4 + k] = acc2[i][1][k] * sc2b[k] + sh2b[k];
-                }
-                if (p.tail.leaky) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.1f * v[k]);
-                }
-                u32x4 o2;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) o2[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
-                if (mw + 16 * i < p.M) *reinterpret_cast<u32x4 *>(dst2 + (size_t)(mw + 16 * i) * 128 + wc * 32 + 8 * fh) = o2;
-            }
-        }
-        Y3_STAMP(4);
-    } else if constexpr (!OUT_F32) {
+    if constexpr (!OUT_F32) {
         // ---- bf16 output: per-wave epilogue, no workgroup barrier ------------------------------------------------------
         // Every wave transposes its own 32 x (32 TN) fp32 blocks through a private LDS scratch (the operand tiles are dead
         // after the loop's last barrier) and stores whole 16-byte pieces of 8 channels: rows of 64 TN bytes per wave, full
@@ -479,6 +311,8 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
         for (int i = 0; i < TM; ++i) {
             const int mw = m0 + (wr * TM + i) * 32;   // first row of this block
             u32x4 rr[NPL];
+            // (round 5: all TM passes' shortcut loads requested up front, so that none queues behind a pass's stores, measured 0.6 % SLOWER,
+            // profiles/r05_ab_bf16_shortcut_hoist.txt: 64 loads per CU in flight at once instead of 32 twice)
             if (res) {   // shortcut operand first: its latency hides behind the accumulator write-out
 #pragma unroll
                 for (int it = 0; it < NPL; ++it) {
@@ -634,7 +468,7 @@ TileInfo conv_bf16_tile_info(int tile) { return kTilesBf16[(tile >= 0 && tile < 
 
 bool conv_bf16_tile_built(int tile) { return tile >= 0 && tile < BF16_TILE_COUNT && kTilesBf16[tile].bm > 0; }
 
-template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false, int MINW = 1, bool M16 = false, bool TAIL = false>
+template <int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, bool DMA = false, int MINW = 1, bool M16 = false>
 static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
 {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
@@ -642,9 +476,8 @@ static hipError_t launch_kb(const ConvArgs &a, hipStream_t s)
     const size_t stages = 2 * (size_t)(BM + BN) * (DMA ? 2 * BK : 2 * BK + 16);
     // epilogue: fp32 output -> one workgroup-wide 32-row block per wave row; bf16 output -> 32 x (32 TN) floats per wave
     const size_t ctile = OUT_F32 ? (size_t)WR * 32 * (BN + 4) * sizeof(float) : (size_t)WR * WC * 32 * 32 * TN * sizeof(float);
-    // TAIL: no epilogue scratch; behind the operand stages the tail conv's first 64-deep weight chunk (16 KB), then the constants of both convs
-    const size_t lds = TAIL ? stages + 128 * 128 + (2 * (size_t)BN + 256) * sizeof(float) : stages > ctile ? stages : ctile;
-    auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, DMA, MINW, M16, TAIL>;
+    const size_t lds = stages > ctile ? stages : ctile;
+    auto k = conv_bf16_mfma<TM, TN, WR, WC, BK, CONCAT, OUT_F32, DMA, MINW, M16>;
     static LdsAttrOnce attr;  // per instantiation
     if (hipError_t e = set_max_lds_once(attr, reinterpret_cast<const void *>(k), (int)lds, a.device); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tilesM * tilesN), dim3(64 * WR * WC), lds, s, a);
@@ -659,19 +492,9 @@ static hipError_t launch_tb(const ConvArgs &a, bool out_f32, hipStream_t s)
     return out_f32 ? launch_kb<TM, TN, WR, WC, BK, false, true, DMA, MINW, M16>(a, s) : launch_kb<TM, TN, WR, WC, BK, false, false, DMA, MINW, M16>(a, s);
 }
 
-bool conv_bf16_tail_fits(const ConvArgs &a, int tile, bool out_f32)
-{
-    return tile == 24 && !out_f32 && !a.src1 && a.Cout == 256 && a.CoutPad == 256 && a.Cin % 64 == 0 && a.dst != nullptr && a.dec.boxes == nullptr &&
-           a.tail.w != nullptr && a.tail.cout == 128 && a.tail.dst != nullptr && a.tail.scale != nullptr && a.tail.shift != nullptr;
-}
-
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s)
 {
     if (!conv_bf16_tile_built(tile)) return hipErrorInvalidValue;
-    if (a.tail.w != nullptr) {   // 3x3 (or any single-source conv) 256 channels wide + the 1x1 that reads it, one launch
-        if (!conv_bf16_tail_fits(a, tile, out_f32)) return hipErrorInvalidValue;
-        return launch_kb<2, 2, 4, 4, 64, false, false, true, 1, true, true>(a, s);
-    }
     const TileInfo t = kTilesBf16[tile];
     if (a.dec.boxes != nullptr && (!out_f32 || t.bn < a.CoutPad)) return hipErrorInvalidValue;   // a fused head needs all its channels in one tile
     if (a.dst == nullptr && a.dec.boxes == nullptr) return hipErrorInvalidValue;

@@ -74,8 +74,6 @@ struct NmsArgs {
     u64 *ws;              // [B][P2] scratch keys, P2 = next pow2 >= N
     int P2;
     float *spill;         // [B][N][4] kept boxes beyond KEPT_CAP
-    const float *canon_boxes;    // box [0,0] and score [0,0] of the BATCH the reference's call sees (TF decides the coordinate canonicalisation
-    const float *canon_scores;   // from that one box): == boxes / scores unless this launch covers a sub-batch (y3_net_detect: one launch per lane)
 };
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
@@ -97,9 +95,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
     float *gspill = p.spill + (size_t)b * p.N * 4;
 
     // canonicalisation flags from box [0,0] of the batch after masking (TF looks at that box only)
-    const float m00 = (p.canon_scores[0] > p.S) ? 1.0f : 0.0f;
-    const bool swap_y = !(p.canon_boxes[0] * m00 <= p.canon_boxes[2] * m00);
-    const bool swap_x = !(p.canon_boxes[1] * m00 <= p.canon_boxes[3] * m00);
+    const float m00 = (p.scores[0] > p.S) ? 1.0f : 0.0f;
+    const bool swap_y = !(p.boxes[0] * m00 <= p.boxes[2] * m00);
+    const bool swap_x = !(p.boxes[1] * m00 <= p.boxes[3] * m00);
 
     if (tid == 0) {
         s_cnt = 0;
@@ -236,12 +234,11 @@ size_t nms_workspace_bytes(int B, int N)
 }
 
 hipError_t launch_nms(const float *boxes, const float *scores, int B, int N, int M, float T, float S, int32_t *sel,
-                      int32_t *num_valid, void *ws, hipStream_t s, const float *canon_boxes, const float *canon_scores)
+                      int32_t *num_valid, void *ws, hipStream_t s)
 {
     const int P2 = next_pow2(N > 1 ? N : 1);
     u64 *keys = static_cast<u64 *>(ws);
-    NmsArgs a{boxes, scores, N, M, T, S, sel, num_valid, keys, P2, reinterpret_cast<float *>(keys + (size_t)B * P2),
-              canon_boxes ? canon_boxes : boxes, canon_scores ? canon_scores : scores};
+    NmsArgs a{boxes, scores, N, M, T, S, sel, num_valid, keys, P2, reinterpret_cast<float *>(keys + (size_t)B * P2)};
     dim3 grid(B), block(NMS_THREADS);
     hipLaunchKernelGGL(nms_kernel, grid, block, 0, s, a);
     return hipGetLastError();

@@ -160,16 +160,6 @@ struct y3_net {
     // y3_net_forward_decode: while set, the three head convs decode their own tiles into these buffers (per scale: first box
     // index, grid size, anchors) instead of writing grids.  Null outside that call.
     const y3::DecodeHead *fuse = nullptr;   // [3], in output order
-    // y3_net_detect on the fused-decode route: while set, every lane enqueues NMS + pack for ITS images on its own stream right behind its last
-    // conv, so that one lane's NMS (one workgroup per image: 32 of 256 CUs busy for ~100 us) runs under the other lane's conv tail
-    struct DetectTail {
-        float *boxes; int64_t *cls; float *scores; int32_t *sel; int32_t *nv; char *ws; char *packed;
-        int n, max_boxes; float iou, score;
-    };
-    const DetectTail *det_tail = nullptr;
-    hipEvent_t canon_ev = nullptr;          // lane 0 -> the other lanes: box [0,0] of the batch (the NMS canonicalisation looks at it) is decoded
-    int tail_mode = 1;             // y3_net_set_tail_fusion: 1 = a 1x1 conv 256 -> 128 that reads a 256-channel conv's output runs inside that conv's launch (bf16 plans, csrc/conv_bf16.hip TAIL)
-    bool tail_mode_set = false;    // y3_net_set_tail_fusion was called (the Y3_TAIL_FUSION tool override then stays out)
     int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 (+ the 1x1 after them) as one kernel when the graph allows it; 2 = conv0 + conv1 only
     bool stem_mode_set = false;    // y3_net_set_stem_fusion was called (the Y3_STEM_MODE tool override then stays out)
     bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
@@ -293,15 +283,12 @@ int choose_tile_x3(const ConvSlot &c, long long M)
 // M = rows of this call (per lane); M_plan = rows of the planned batch.  The MFMA SHAPE (16x16x32 vs 32x32x16: two K groupings,
 // results differ in the last bits) is decided from plan-time quantities only, so that an image's result does not depend on the
 // batch or lane it runs in (y3_net_set_lanes: "results are unchanged"); the tile SIZE within one shape follows the call.
-int choose_tile_bf16(const ConvSlot &c, long long M, long long M_plan, bool bf16_out, bool tail_candidate = false)
+int choose_tile_bf16(const ConvSlot &c, long long M, long long M_plan, bool bf16_out)
 {
     auto blocks = [&](int t) {
         y3::TileInfo s = y3::conv_bf16_tile_info(t);
         return ((M + s.bm - 1) / s.bm) * (c.cout_pad / s.bn);
     };
-    // a 1x1 conv that may run as the tail of its producer's launch (16x16x32 MFMAs there) keeps that MFMA shape when a call runs it on
-    // its own -- the producer of a small call takes a tile without the tail -- so that an image's bits do not depend on the call's size
-    if (tail_candidate) return blocks(27) >= 512 ? 27 : 29;
     // large 3x3 convs: the 16x16x32 form once the PLANNED batch fills the chip with 256x256 tiles of 16 waves (tile 24 wins every
     // such signature of the 64- and 128-image tables, tuning/bf16_b*_s416.json); smaller calls of the same plan take the 128x128 /
     // 64x128 tiles of the same MFMA shape (27, 29)
@@ -434,32 +421,6 @@ static bool stem_conv2_applicable(const y3_net *net)
     return true;
 }
 
-// Ops oi (conv A) and oi + 1 (conv B) of a bf16 plan form a "tail pair": B is a 1x1 / stride-1 conv 256 -> 128 whose only input is A's
-// output, A any single-source conv with exactly 256 output channels (one 256x256 tile spans them all), neither writes an fp32 net output.
-// Then A's launch computes B from the output tile it still holds whenever it runs on the 256x256 16-wave tile (bf16 tile 24): the residual
-// blocks' bottleneck convs at 52 x 52 and the two of the last neck (reference: config/models/yolov3/backbone.yaml, neck2.yaml -> core/parse_model.py:27-52).
-// A property of the graph and the plan only -- never of the rows of a call.
-static bool tail_pair_graph(const y3_net *net, int oi)   // the graph and the plan's dtype only (the planner's liveness uses this form)
-{
-    if (net->dtype != Y3_DTYPE_BF16 || oi < 0 || oi + 1 >= (int)net->ops.size()) return false;
-    if (net->ops[oi].kind != 0 || net->ops[oi + 1].kind != 0) return false;
-    const ConvSlot &A = net->convs[net->ops[oi].index], &B = net->convs[net->ops[oi + 1].index];
-    auto f32_out = [&](int t) { return (t == net->outputs[0] || t == net->outputs[1] || t == net->outputs[2]) && !net->staged[t]; };
-    if (A.first_layer || A.d.src1 >= 0 || A.d.cout != 256 || A.cout_pad != 256 || A.d.cin % 64 || f32_out(A.d.dst)) return false;
-    if (B.d.size != 1 || B.d.stride != 1 || B.d.cin != 256 || B.d.cout != 128 || B.cout_pad != 128 || B.d.src0 != A.d.dst || B.d.src1 >= 0 ||
-        B.d.residual >= 0 || f32_out(B.d.dst) || B.d.dst == A.d.dst)
-        return false;
-    return true;
-}
-static bool tail_pair(const y3_net *net, int oi)
-{
-    if (!net->tail_mode || net->early_ops > 0) return false;
-    if (net->stem_fused && oi < 3) return false;       // the fused stem owns the first three convs
-    return tail_pair_graph(net, oi);
-}
-// ... and B of such a pair (so that a call that runs it on its own picks a tile of the tail's MFMA shape)
-static bool tail_candidate(const y3_net *net, int oi) { return tail_pair(net, oi - 1); }
-
 // Does this conv's launch write an fp32 net output directly (bf16 / plane-split plans)?  Mirrors the `staged` rule of y3_net_plan: an
 // output that another op reads, or that a shortcut / first-layer conv writes, stays in the arena in the mode's format instead.
 static bool writes_f32_output(const y3_net *net, const ConvSlot &c)
@@ -563,7 +524,6 @@ void y3_net_destroy(y3_net *net)
     free_plan(net);
     if (net->fork_ev) {
         (void)hipEventDestroy(net->fork_ev);
-        if (net->canon_ev) (void)hipEventDestroy(net->canon_ev);
         for (int i = 0; i < Y3_MAX_LANES; ++i) {
             (void)hipStreamDestroy(net->lane_stream[i]);
             (void)hipEventDestroy(net->join_ev[i]);
@@ -774,15 +734,6 @@ try {
 }
 Y3_CATCH("y3_net_set_stem_fusion")
 
-y3_status y3_net_set_tail_fusion(y3_net *net, int on)
-try {
-    if (!net || on < 0 || on > 1) return fail(Y3_ERR_INVALID, "y3_net_set_tail_fusion: argument must be 0 or 1");
-    net->tail_mode = on;
-    net->tail_mode_set = true;
-    return Y3_OK;
-}
-Y3_CATCH("y3_net_set_tail_fusion")
-
 y3_status y3_net_set_k_chunk(y3_net *net, int channels)
 try {
     if (!net || channels < -1 || (channels > 0 && channels % 32)) return fail(Y3_ERR_INVALID, "y3_net_set_k_chunk: -1, 0 or a multiple of 32 channels");
@@ -824,7 +775,6 @@ static y3_status ensure_lanes(y3_net *net)
 {
     if (net->fork_ev) return Y3_OK;
     HIP_TRY(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&net->canon_ev, hipEventDisableTiming));
     for (int i = 0; i < Y3_MAX_LANES; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&net->lane_stream[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&net->join_ev[i], hipEventDisableTiming));
@@ -888,15 +838,6 @@ try {
         for (int k = 0; k < 3; ++k)
             if (net->staged[net->outputs[k]]) last[net->outputs[k]] = (int)net->ops.size();        // alive until the final conversion
     }
-    // A 1x1 conv that may run as the tail of its producer's launch (conv_bf16.hip TAIL) writes its output DURING the producer's op: the tensor is
-    // live one op earlier than the op list says.  (Without this the planner hands it the block of the producer's own input -- the previous
-    // block's bottleneck tensor, same size, dead "after" the producer -- and the launch overwrites what it is still reading.)  Whatever the
-    // fusion switch says now: y3_net_set_tail_fusion may be called after the plan.
-    for (int i = 0; i + 1 < (int)net->ops.size(); ++i)
-        if (tail_pair_graph(net, i)) {
-            const int t = net->convs[net->ops[i + 1].index].d.dst;
-            if (first[t] > i) first[t] = i;
-        }
     // chunked leading segment: every op before the (early_convs)-th conv; tensors it writes get blocks of their own,
     // laid out densely by image, because they are rewritten chunk after chunk while earlier chunks' results are still live
     net->early_ops = 0;
@@ -955,10 +896,6 @@ try {
     }
     net->stem_fused = net->stem_mode && stem_applicable(net);
     net->stem_conv2 = net->stem_fused && net->stem_mode == 1 && stem_conv2_applicable(net);
-    {   // Y3_TAIL_FUSION (tools: same-process-tree A/B): overrides the default, not an explicit setter call
-        static const int env = [] { const char *e = getenv("Y3_TAIL_FUSION"); return e ? atoi(e) : -1; }();
-        if (env >= 0 && env <= 1 && !net->tail_mode_set) net->tail_mode = env;
-    }
     if (net->nclasses > 0) {   // scratch of y3_net_detect: no allocation inside the stream-ordered call
         size_t off[9], n_boxes, gelems[3];
         int32_t gs[3];
@@ -1105,16 +1042,6 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 if (ms_out && o.index < n_ms) ms_out[o.index] = 0.0f;
                 continue;
             }
-            // the tile conv `slot` of a bf16 plan takes for this call (table / forced tile, else the heuristic)
-            auto bf16_tile = [&](const ConvSlot &cs, int op_index, bool to_f32) {
-                const long long ho = net->image_size / cs.d.out_div;
-                return cs.tile_bf16 >= 0 ? cs.tile_bf16
-                                         : choose_tile_bf16(cs, (long long)nb * ho * ho, (long long)net->max_batch * ho * ho, !to_f32, tail_candidate(net, op_index));
-            };
-            if (bf && oi > 0 && tail_pair(net, oi - 1) && bf16_tile(net->convs[net->ops[oi - 1].index], oi - 1, false) == 24) {
-                if (ms_out && o.index < n_ms) ms_out[o.index] = 0.0f;   // ran as the tail of the previous conv's launch
-                continue;
-            }
             if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
             hipError_t e;
             if (net->stem_fused && oi == 1) {
@@ -1173,23 +1100,11 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * 2);
                 const bool out_f32 = is_out(d.dst);
                 if (d.residual >= 0 && out_f32) return fail(Y3_ERR_INVALID, "conv %d: residual on a head output is not supported in bf16 mode", o.index);
-                int tile = bf16_tile(c, oi, out_f32);
+                int tile = c.tile_bf16 >= 0 ? c.tile_bf16 : choose_tile_bf16(c, a.M, (long long)net->max_batch * a.Ho * a.Wo, !out_f32);
                 if (head >= 0 && y3::conv_bf16_tile_info(tile).bn != 256) {   // a box's logits must meet in one workgroup: all 256 channels in the tile
                     const bool m16 = tile >= 24 && tile <= 29;                // keep the MFMA shape of the plan's tile: same K grouping, same bits
                     const bool big = (a.M + 255) / 256 >= 256;                // 256x256 once it fills the chip, else 128x256 (16 waves both)
                     tile = m16 ? (big ? 24 : 26) : (big ? 17 : 19);
-                }
-                if (head < 0 && tile == 24 && tail_pair(net, oi)) {   // the 1x1 conv that reads this output: same launch (conv_bf16.hip TAIL)
-                    const ConvSlot &tb = net->convs[net->ops[oi + 1].index];
-                    a.tail.w = tb.wbf_dev;
-                    a.tail.scale = tb.scale_dev;
-                    a.tail.shift = tb.shift_dev;
-                    a.tail.dst = ptr(tb.d.dst);
-                    a.tail.cout = tb.d.cout;
-                    a.tail.leaky = tb.d.leaky;
-                    a.tail.dst_bytes = (unsigned)bytes(tb.d.dst);
-                    if (!a.tail.dst || !a.tail.w) return fail(Y3_ERR_STATE, "conv %d: tensor not planned", net->ops[oi + 1].index);
-                    if (!y3::conv_bf16_tail_fits(a, tile, out_f32)) return fail(Y3_ERR_STATE, "conv %d: the fused 1x1 tail does not fit its producer's launch", net->ops[oi + 1].index);
                 }
                 e = y3::launch_conv_bf16(a, tile, out_f32, s);
             } else if (c.first_layer) {
@@ -1286,23 +1201,7 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
         }
         return run_slice(net, images, grids, b0, nb, st, ms_out, n_ms, lane, nl, k_early, -1);
     };
-    // NMS + pack of images [b0, b0 + nb) on stream st (y3_net_detect, fused-decode route); wait_canon: behind lane 0's first head
-    auto detect_tail = [&](int b0, int nb, hipStream_t st, bool wait_canon) -> y3_status {
-        const y3_net::DetectTail &t = *net->det_tail;
-        if (wait_canon) HIP_TRY(hipStreamWaitEvent(st, net->canon_ev, 0));
-        hipError_t e = y3::launch_nms(t.boxes + (size_t)b0 * t.n * 4, t.scores + (size_t)b0 * t.n, nb, t.n, t.max_boxes, t.iou, t.score,
-                                      t.sel + (size_t)b0 * t.max_boxes, t.nv + b0, t.ws + y3::nms_workspace_bytes(b0, t.n), st, t.boxes, t.scores);
-        if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_detect: NMS launch: %s", hipGetErrorString(e));
-        e = y3::launch_pack(t.boxes + (size_t)b0 * t.n * 4, t.cls + (size_t)b0 * t.n, t.scores + (size_t)b0 * t.n, t.sel + (size_t)b0 * t.max_boxes,
-                            t.nv + b0, nb, t.n, t.max_boxes, t.packed + (size_t)b0 * t.max_boxes * 7 * 4, st);
-        if (e != hipSuccess) return fail(Y3_ERR_HIP, "y3_net_detect: pack launch: %s", hipGetErrorString(e));
-        return Y3_OK;
-    };
-    if (lanes == 1) {
-        y3_status st = run_lane(0, batch, s, 0, 1);
-        if (st == Y3_OK && net->det_tail) st = detect_tail(0, batch, s, false);
-        return st;
-    }
+    if (lanes == 1) return run_lane(0, batch, s, 0, 1);
     if (y3_status st = ensure_lanes(net); st != Y3_OK) return st;
     HIP_TRY(hipEventRecord(net->fork_ev, s));
     // equal sub-batches (measured with tools/lanes_sweep.py: weighted 2:3 / 3:4:5 splits were 2-3 % slower)
@@ -1336,17 +1235,12 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
                 if (k && l > 0 && op == 0) HIP_TRY(hipStreamWaitEvent(net->lane_stream[l], net->join_ev[l - 1], 0));
                 y3_status st = run_slice(net, images, grids, start[l], nb, net->lane_stream[l], nullptr, 0, l, lanes, op, op + 1);
                 if (st != Y3_OK) return st;
-                // lane 0 has decoded the first scale of its images -- box [0,0] of the batch among them: the other lanes' NMS may look at it
-                if (net->det_tail && l == 0 && net->ops[op].kind == 0 && net->convs[net->ops[op].index].d.dst == net->outputs[0])
-                    HIP_TRY(hipEventRecord(net->canon_ev, net->lane_stream[0]));
                 // (join_ev[l] is re-recorded at the end of the lane below: an event names its latest record only for waits enqueued after it)
                 if (k && l + 1 < lanes && op == k - 1) HIP_TRY(hipEventRecord(net->join_ev[l], net->lane_stream[l]));
             }
     }
     for (int l = 0; l < lanes; ++l) {
         if (start[l + 1] <= start[l]) continue;
-        if (net->det_tail && k_early == 0)
-            if (y3_status st = detect_tail(start[l], start[l + 1] - start[l], net->lane_stream[l], l > 0); st != Y3_OK) return st;
         HIP_TRY(hipEventRecord(net->join_ev[l], net->lane_stream[l]));
         HIP_TRY(hipStreamWaitEvent(s, net->join_ev[l], 0));
     }
@@ -1736,18 +1630,9 @@ try {
     float *boxes = reinterpret_cast<float *>(b + o_box), *scores = reinterpret_cast<float *>(b + o_score);
     int64_t *cls = reinterpret_cast<int64_t *>(b + o_cls);
     int32_t *sel = reinterpret_cast<int32_t *>(b + o_sel);
-    // conv program with the head convs decoding their own tiles (grids neither written nor read back) where the graph allows it; on that
-    // route every lane runs NMS + pack for its own images behind its last conv (same kernels, same per-image arithmetic, the batch's box
-    // [0,0] handed to every launch: bit-identical to the batch-wide launches below)
-    if (heads_can_decode(net) && net->early_ops == 0) {
-        if (!(iou_threshold > 0.0f) && score_threshold < 0.0f)
-            return fail(Y3_ERR_INVALID, "y3_nms_padded: iou_threshold <= 0 together with score_threshold < 0 is not supported");
-        y3_net::DetectTail dt{boxes, cls, scores, sel, num_valid_dev, b + o_ws, static_cast<char *>(packed_dev), (int)n, max_boxes, iou_threshold, score_threshold};
-        net->det_tail = &dt;
-        y3_status st = y3_net_forward_decode(net, images_dev, batch, anchors_host, boxes, cls, scores, stream);
-        net->det_tail = nullptr;
-        return st;
-    }
+    // conv program with the head convs decoding their own tiles (grids neither written nor read back) where the graph allows it.
+    // (Round 5 ran NMS + pack per lane, on each lane's stream behind its last conv: bit-identical and 0.2 % slower under graph replay -- the NMS
+    // workgroups take CUs from the other lane's last convs; profiles/r05_ab_bf16_lane_nms.txt.  Batch-wide launches behind the join again.)
     y3_status st = y3_net_forward_decode(net, images_dev, batch, anchors_host, boxes, cls, scores, stream);
     if (st != Y3_OK) return st;
     st = y3_nms_padded(boxes, scores, batch, (int)n, max_boxes, iou_threshold, score_threshold, sel, num_valid_dev,

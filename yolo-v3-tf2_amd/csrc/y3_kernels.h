@@ -8,20 +8,6 @@
 
 namespace y3 {
 
-// The 1x1 conv that READS this launch's output, computed by the same launch from the output tile it still holds (bf16 plans, round 5:
-// conv_bf16.hip TAIL).  A residual block's 1x1 (Cin -> Cin / 2; reference: config/models/yolov3/backbone.yaml, core/parse_model.py:27-52)
-// follows a 3x3 whose 256 output channels one 256x256 tile spans: pointwise, so no halo; its launch, its read of the tensor and its
-// prologue / epilogue / partially filled rounds disappear (profiles/r05_gate_block_fusion_bf16.txt).  w == nullptr: no tail.
-struct TailConv {
-    const void *w;         // packed [cout][cin] bf16 (cin = the producing conv's Cout = 256, k = c)
-    const float *scale;    // [cout]
-    const float *shift;    // [cout]
-    void *dst;             // [B,Ho,Wo,cout] bf16
-    int cout;              // 128
-    int leaky;
-    unsigned dst_bytes;
-};
-
 // One fused conv launch: Conv2D [+BN] [+LeakyReLU(0.1)] [+shortcut add], optional
 // (nearest-x2-upsampled src0) (+) src1 channel concat in the A-operand gather.
 struct ConvArgs {
@@ -54,7 +40,6 @@ struct ConvArgs {
     unsigned long long *clk_stamps;   // [4]
     int n_cus;             // compute units of the net's device, read once by y3_net_plan: sizes the grids of the persistent kernels (conv_res_*.hip)
     int device;            // the net's device index (the launch goes there: Y3_ENTER_DEVICE); -1 = not known, launchers ask the runtime
-    TailConv tail;         // bf16 tile 24 only
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to the
@@ -125,8 +110,6 @@ static constexpr int BF16_TILE_COUNT = 37;   // 32: the weight-resident 3x3 kern
 TileInfo conv_bf16_tile_info(int tile);
 bool conv_bf16_tile_built(int tile);
 hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream_t s);
-// can this launch (tile, shape) also run the 1x1 conv described by a.tail?
-bool conv_bf16_tail_fits(const ConvArgs &a, int tile, bool out_f32);
 // weight-resident 3x3 / stride-1 conv for Cin = 32 / 64 (conv_res_bf16.hip): the early short-K layers of the bf16 path
 bool conv_res_bf16_fits(const ConvArgs &a);
 hipError_t launch_conv_res_bf16(const ConvArgs &a, hipStream_t s);
@@ -165,9 +148,8 @@ hipError_t launch_class_scores(const float *conf, const float *probs, size_t n, 
 hipError_t launch_resize(const void *src, int is_u8, int H, int W, int pix_stride, float *dst, int S, hipStream_t s);
 
 size_t nms_workspace_bytes(int B, int N);
-// canon_boxes / canon_scores: box [0,0] / score [0,0] of the whole batch when this launch covers a sub-batch (null: the launch's own first box)
 hipError_t launch_nms(const float *boxes, const float *scores, int B, int N, int M, float T, float S, int32_t *sel,
-                      int32_t *num_valid, void *ws, hipStream_t s, const float *canon_boxes = nullptr, const float *canon_scores = nullptr);
+                      int32_t *num_valid, void *ws, hipStream_t s);
 hipError_t launch_pack(const float *boxes, const int64_t *cls, const float *scores, const int32_t *sel,
                        const int32_t *nv, int B, int N, int M, void *packed, hipStream_t s);
 
