@@ -37,8 +37,10 @@ def residual_blocks(p):
     return out
 
 
-def drop_stage(p, divs):
-    """A copy of the program in which the blocks at the given spatial divisors keep only their stage's first 1x1."""
+def drop_stage(p, divs, free_shortcut=False):
+    """A copy of the program in which the blocks at the given spatial divisors keep only their stage's first 1x1.  free_shortcut: the
+    3x3 convs of those blocks (the first one too) also lose their shortcut operand -- the fused kernel takes it from the input patch
+    it has in LDS anyway, so its separate read disappears as well (wrong values, timing only)."""
     q = copy.deepcopy(p)
     blocks = residual_blocks(q)
     first = {}
@@ -46,6 +48,8 @@ def drop_stage(p, divs):
     for i1, i3, div in blocks:
         if div not in divs:
             continue
+        if free_shortcut:
+            q.ops[i3].residual = -1
         if div not in first:
             first[div] = q.ops[i1].dst
             continue
@@ -62,6 +66,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--free-shortcut", action="store_true", help="bound for the weight-resident fused block at 104^2: also drop the 3x3 convs' shortcut reads")
     a = ap.parse_args()
     dt = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16}[a.dtype]
     p = load_program(os.path.join(ROOT, "config/models/yolov3/model.yaml"), 80)
@@ -74,10 +79,12 @@ def main():
     print(f"# {a.dtype}, {B} x {S}^2, tuning table of the plan; residual blocks per stage (grid size: count): "
           + ", ".join(f"{S // d}: {n}" for d, n in sorted(per_div.items())))
     variants = [("shipped", None)] + [(f"no 1x1 launches @{S // d}", {d}) for d in sorted(per_div) if per_div[d] > 1] + [("no 1x1 launches, all stages", set(per_div))]
+    if a.free_shortcut:   # the HBM-bound early stages only: 1x1 launches gone AND the 3x3's shortcut read gone
+        variants = [("shipped", None)] + [(f"no 1x1 launch, no shortcut read @{S // d}", {d}) for d in sorted(per_div) if per_div[d] > 1 and S // d >= 104]
     nets = []
     x = torch.rand((B, S, S, 3), device="cuda")
     for name, divs in variants:
-        q, nd = (p, 0) if divs is None else drop_stage(p, divs)
+        q, nd = (p, 0) if divs is None else drop_stage(p, divs, a.free_shortcut)
         net = runtime.Net(q)
         net.load_weights(w)
         net.plan(B, S, dt)

@@ -101,6 +101,7 @@ SYMBOLS = {
     "y3_net_set_xcd_mode": (_i, [_vp, _i]),
     "y3_net_set_k_chunk": (_i, [_vp, _i]),
     "y3_net_set_stem_fusion": (_i, [_vp, _i]),
+    "y3_net_set_block_fusion": (_i, [_vp, _i]),
     "y3_net_measure_sclk": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _fp, _vp]),
     "y3_net_measure_sclk_conv": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _i, _fp, _vp]),
     "y3_net_measure_sclk_all": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _fp, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),
