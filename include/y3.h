@@ -149,13 +149,6 @@ y3_status y3_net_keep_activations(y3_net *net, int keep);
  * bf16 where the pipeline stores it; against the one-launch-per-conv form a fraction of a percent of conv0's bf16 values round
  * the other way (bounded by tests/test_gpu_parity.py::test_fused_stem_bf16_matches_oracle_and_the_two_launch_form). */
 y3_status y3_net_set_stem_fusion(y3_net *net, int on);
-/* bf16 plans (without keep_activations).  1 (default): an early residual block -- 1x1 conv Cx -> Cx / 2 followed by the 3x3 conv Cx / 2 -> Cx that adds the
- * block's input, Cx = 64 or 128: the block at 208 x 208 and the two at 104 x 104 of the reference's backbone.yaml (core/parse_model.py:27-52, :143-160)
- * -- runs as ONE launch (csrc/conv_block_bf16.hip): the 1x1 is computed for the 3x3's input patch in LDS and its output tensor is never written, the
- * shortcut is read from the same patch.  These launches are bound by HBM bytes; the block moves its input once instead of twice and the middle tensor
- * not at all.  Bit-identical to the two-launch form (tests/test_gpu_parity.py::test_bf16_fused_block_bit_identical_to_two_launches).  The 1x1 behind the
- * fused stem then belongs to this launch, not to the stem's.  0: one launch per conv. */
-y3_status y3_net_set_block_fusion(y3_net *net, int on);
 /* Measurement aid (bench.py): the shader clock the chip holds under this network's load.  Runs `forwards` forwards back to
  * back (grids_dev as for y3_net_forward); in the last one, thread 0 of the middle workgroup of the conv with the most FLOPs (fp32
  * plans: an MFMA conv launch; bf16 plans: the fused stem kernel) reads s_memtime and s_memrealtime at its entry and after

@@ -143,8 +143,9 @@ def test_no_extern_c_entry_without_the_barrier():
 
 
 def test_tile_built_reports_the_default_tile_set():
-    """y3_tile_built (no GPU needed): the library holds exactly the tiles of the Python-side tables; the ids of the ablations and
-    schedules that lost their A/Bs in rounds 1-3 (probes, stream-K, residual prefetch, the pipelined bf16 tile) are retired."""
+    """y3_tile_built (no GPU needed): the library holds exactly the tiles of the Python-side tables, and exactly the tiles some plan can select;
+    every other id of rounds 1-4 (ablations, stream-K, residual prefetch, pipelined / tap-row-reuse / four-wave bf16 tiles, and the tuner
+    candidates no table kept) is retired."""
     from yolo_v3_tf2_amd import _lib
     f32 = [t for t in range(len(_lib.TILES) + 16) if _lib.tile_built(_lib.Y3_DTYPE_F32, t)]
     bf16 = [t for t in range(len(_lib.TILES_BF16) + 4) if _lib.tile_built(_lib.Y3_DTYPE_BF16, t)]
@@ -153,14 +154,23 @@ def test_tile_built_reports_the_default_tile_set():
     assert not _lib.tile_built(_lib.Y3_DTYPE_F32, -1) and not _lib.tile_built(_lib.Y3_DTYPE_F32, len(_lib.TILES))
     assert not _lib.tile_built(7, 0)
     assert x3 == list(_lib.TILES_X3_BUILT) and x2 == list(_lib.TILES_X2_BUILT)
-    assert f32 == [t for t in range(len(_lib.TILES)) if _lib.TILES[t][0] > 0] == list(range(20)) + [23, 24] + list(range(26, len(_lib.TILES)))
-    assert bf16 == [t for t in range(len(_lib.TILES_BF16)) if _lib.TILES_BF16[t][0] > 0] == list(range(20)) + list(range(21, 33))   # 32: weight-resident 3x3; 33..36: retired in round 5
-    assert _lib.RETIRED_TILES == (20, 21, 22, 25)
+    assert f32 == [t for t in range(len(_lib.TILES)) if _lib.TILES[t][0] > 0]
+    assert bf16 == [t for t in range(len(_lib.TILES_BF16)) if _lib.TILES_BF16[t][0] > 0]
+    assert x3 == [t for t in range(len(_lib.TILES_X3)) if _lib.TILES_X3[t][0] > 0 and t not in (26, 27)]      # 26, 27: two-plane mode only
+    assert all(_lib.TILES_X3[t][0] > 0 for t in x2)
     # every tile a committed tuning table names is in the default set
     import glob
     import json
+    named = {}
     for f in glob.glob(os.path.join(ROOT, "yolo-v3-tf2_amd", "tuning", "*.json")):
         tag = os.path.basename(f).split("_")[0]
         dt = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3, "f32x2": _lib.Y3_DTYPE_F32X2}[tag]
         for sig, t in json.load(open(f))["tiles"].items():
             assert t < 0 or _lib.tile_built(dt, t), (f, sig, t)
+            if t >= 0:
+                named.setdefault(tag, set()).add(t)
+    # ... and nothing else is: every tile id the library builds is named by a packaged table or picked by the library's heuristics
+    # (_lib.HEURISTIC_TILES mirrors choose_tile* / the head-decode fallback of csrc/y3_api.cpp) -- no kernel ships that no plan can select
+    for tag, built in (("f32", f32), ("bf16", bf16), ("f32x3", x3), ("f32x2", x2)):
+        assert set(built) == named.get(tag, set()) | set(_lib.HEURISTIC_TILES[tag]), (tag, sorted(set(built) ^ (named.get(tag, set()) | set(_lib.HEURISTIC_TILES[tag]))))
+

@@ -87,6 +87,7 @@ def main():
     # The chip warms up over the run (round 3: 10.07 -> 10.17 ms with nothing changed), so a candidate is compared with
     # the CURRENT tile measured right before it, and a winner must win a second, re-measured pair.
     cands = [int(v) for v in a.tiles.split(",")] if a.tiles else CANDIDATES[a.dtype]
+    cands = [t for t in cands if _lib.tile_built(dt, t)]      # (round 5: only tiles some plan selects are built; new candidates need a switch case)
     only = [v for v in a.only.split(",") if v]
     for sig in sorted(sigs, key=lambda s: -sigs[s]["flops"]):
         if only and not any(v in sig for v in only):

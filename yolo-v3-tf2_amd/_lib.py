@@ -17,47 +17,50 @@ LIB_PATH = os.environ.get("Y3_LIB_PATH") or os.path.join(PACKAGE_DIR, "lib", "li
 Y3_OK = 0
 Y3_DTYPE_F32, Y3_DTYPE_BF16, Y3_DTYPE_F32X3, Y3_DTYPE_F32X2 = 0, 1, 2, 3
 DTYPE_TAGS = {Y3_DTYPE_F32: "f32", Y3_DTYPE_BF16: "bf16", Y3_DTYPE_F32X3: "f32x3", Y3_DTYPE_F32X2: "f32x2"}
-TILES_X2_BUILT = (0, 1, 2, 3, 4, 6, 8, 9, 10, 12, 26, 27, 30, 31, 32, 33)
-TILES_X3_BUILT = tuple(range(28)) + (30,)
+TILES_X2_BUILT = (0, 1, 2, 3, 4, 8, 12, 26, 27)
+TILES_X3_BUILT = (0, 1, 2, 3, 4, 8, 9, 12, 13, 14)
 Y3_AUX_ADD, Y3_AUX_UPSAMPLE2X, Y3_AUX_CONCAT = 0, 1, 2
 # (BM, BN, waves, LDS stages) of every tile id of the fp32 MFMA conv kernel (mirror of kTiles in csrc/conv_f32.hip)
-TILES = [(128, 128, 4, 2), (256, 64, 4, 2), (256, 32, 4, 2), (128, 64, 4, 2), (64, 128, 4, 2), (64, 64, 4, 2),
-         (128, 128, 4, 1), (256, 64, 4, 1), (256, 32, 4, 1), (128, 64, 4, 1), (64, 128, 4, 1), (64, 64, 4, 1),
-         (128, 128, 8, 1), (128, 128, 8, 2), (128, 128, 16, 1), (128, 128, 16, 2),
-         (256, 128, 16, 1), (128, 64, 8, 1), (256, 64, 8, 1), (128, 64, 8, 2),
-         (0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0),           # 20..22: retired ids (y3_tile_built answers 0)
-         (128, 128, 4, 1), (128, 128, 4, 1),                # 23/24: 128x128 within 3 / 4 waves per SIMD of registers
-         (0, 0, 0, 0),                                      # 25: retired id
-         (64, 128, 4, 2), (64, 64, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (256, 32, 4, 2),  # 26..30: LDS-DMA operand loads
+# (0, 0, 0, 0): a retired id (y3_tile_built answers 0).  Round 5: only tiles a packaged tuning table or the library's heuristic selects are built.
+_Z = (0, 0, 0, 0)
+TILES = [_Z, _Z, _Z, _Z, _Z, _Z,
+         (128, 128, 4, 1), _Z, (256, 32, 4, 1), (128, 64, 4, 1), (64, 128, 4, 1), (64, 64, 4, 1),   # 6..11: single LDS stage
+         (128, 128, 8, 1), _Z, _Z, _Z,
+         _Z, (128, 64, 8, 1), _Z, _Z,
+         _Z, _Z, _Z,
+         (128, 128, 4, 1), _Z,                              # 23: 128x128 within 3 waves per SIMD of registers
+         _Z,
+         (64, 128, 4, 2), (64, 64, 4, 2), _Z, _Z, _Z,       # 26, 27: LDS-DMA operand loads, two stages
          (64, 128, 4, 1), (64, 64, 4, 1),                   # 31, 32: LDS-DMA, single LDS stage
-         (128, 64, 8, 2),                                   # 33: weight-resident 3x3 / stride 1 / Cin 32 (csrc/conv_res_f32.hip)
-         (32, 128, 4, 1)]                                   # 34: 32x128 on one row of four waves, LDS-DMA, single stage
+         (128, 64, 8, 2)]                                   # 33: weight-resident 3x3 / stride 1 / Cin 32 (csrc/conv_res_f32.hip)
 RETIRED_TILES = tuple(i for i, t in enumerate(TILES) if t[0] == 0)   # ids y3_tile_built answers 0 for
 # three-plane (fp32-accurate on bf16 MFMA) kernel tiles: (BM, BN, waves, BK)
-TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), (256, 64, 4, 32),
-            (128, 64, 4, 64), (64, 64, 4, 64), (128, 256, 8, 32),
-            (128, 128, 4, 32), (256, 128, 8, 32), (128, 256, 8, 32), (128, 128, 8, 32), (128, 64, 4, 32), (64, 128, 4, 32),
-            (64, 64, 4, 32),   # 9..11, 13..15: single LDS stage
-            (256, 256, 8, 16), (256, 128, 8, 16), (128, 256, 8, 16), (128, 128, 4, 16),   # 16..19: 16-deep K stages
-            (256, 128, 8, 32), (128, 256, 8, 32), (128, 128, 4, 32), (128, 128, 8, 32),   # 20..23: interleaved DMA issue
-            (256, 128, 8, 32), (128, 256, 8, 32),                                         # 24..25: + pinned issue order
-            (256, 128, 16, 32), (128, 256, 16, 32),                                       # 26..27: 16 waves
-            (0, 0, 0, 32), (0, 0, 0, 32),                                                 # 28..29: retired ids
-            (128, 128, 8, 32), (256, 128, 16, 32), (256, 128, 8, 32), (128, 256, 16, 32)]  # 30..33: three LDS stages
+_Z32, _Z64, _Z16 = (0, 0, 0, 32), (0, 0, 0, 64), (0, 0, 0, 16)
+TILES_X3 = [(128, 128, 4, 32), (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 32), (256, 128, 8, 32), _Z32,
+            _Z64, _Z64, (128, 256, 8, 32),
+            (128, 128, 4, 32), _Z32, _Z32, (128, 128, 8, 32), (128, 64, 4, 32), (64, 128, 4, 32), _Z32,   # 9, 13, 14: single LDS stage
+            _Z16, _Z16, _Z16, _Z16,
+            _Z32, _Z32, _Z32, _Z32,
+            _Z32, _Z32,
+            (256, 128, 16, 32), (128, 256, 16, 32),                                       # 26..27: 16 waves (two-plane mode)
+            _Z32, _Z32,
+            _Z32, _Z32, _Z32, _Z32]
 # bf16 kernel tiles: (BM, BN, waves, BK)
-TILES_BF16 = [(128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (128, 32, 4, 64),
-              (128, 64, 4, 32), (64, 64, 4, 32), (64, 128, 4, 64),
-              (128, 128, 4, 64), (256, 128, 8, 64), (128, 64, 4, 64), (64, 64, 4, 64), (64, 128, 4, 64), (128, 256, 8, 64),  # 8..13: LDS-DMA loads
-              (256, 256, 8, 64), (256, 128, 4, 64), (128, 256, 4, 64),  # 14..16: LDS-DMA, bigger wave tiles
-              (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64),  # 17..19: LDS-DMA, 16 waves
-              (0, 0, 0, 64),      # 20: retired id (the pipelined tile of round 2)
-              (128, 256, 8, 32), (256, 128, 8, 32), (128, 128, 4, 32),  # 21..23: LDS-DMA, BK 32: several workgroups per CU
-              (256, 256, 16, 64), (256, 128, 16, 64), (128, 256, 16, 64),  # 24..26: tiles 17..19 on 16x16x32 MFMAs
-              (128, 128, 4, 64), (128, 64, 4, 64), (64, 128, 4, 64),       # 27..29: tiles 8, 10, 12 on 16x16x32 MFMAs
-              (128, 64, 4, 32), (64, 64, 4, 32),                          # 30, 31: LDS-DMA, BK 32, 64 output channels
+TILES_BF16 = [(128, 128, 4, 64), _Z64, _Z64, (64, 64, 4, 64), (128, 32, 4, 64),
+              (128, 64, 4, 32), (64, 64, 4, 32), _Z64,
+              (128, 128, 4, 64), _Z64, (128, 64, 4, 64), (64, 64, 4, 64), (64, 128, 4, 64), _Z64,  # 8..13: LDS-DMA loads
+              _Z64, _Z64, _Z64,
+              (256, 256, 16, 64), _Z64, (128, 256, 16, 64),              # 17..19: LDS-DMA, 16 waves
+              _Z64,
+              _Z32, (256, 128, 8, 32), _Z32,                               # 21..23: LDS-DMA, BK 32, two workgroups per CU
+              (256, 256, 16, 64), _Z64, (128, 256, 16, 64), (128, 128, 4, 64), _Z64, (64, 128, 4, 64),   # 24..29: 16x16x32 MFMAs
+              _Z32, _Z32,
               (128, 64, 8, 32),                                           # 32: weight-resident 3x3 / stride 1, Cin 32 / 64 (csrc/conv_res_bf16.hip)
-              (0, 0, 0, 64), (0, 0, 0, 64), (0, 0, 0, 64), (0, 0, 0, 64)]  # 33..36: retired in round 5 (tap-row reuse, the four-wave 256x256 tile: no plan selected them)
-TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 or i == 34 else "") + ("res" if i == 33 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
+              _Z64, _Z64, _Z64, _Z64]                                     # 33..36: retired in round 5
+# Tile ids the library's own heuristics can pick (choose_tile* and the head-decode fallback in csrc/y3_api.cpp); with the packaged tuning tables they
+# name every tile the library builds (tests/test_abi.py::test_tile_built_reports_the_default_tile_set)
+HEURISTIC_TILES = {"f32": (8, 10, 11, 33), "bf16": (4, 5, 6, 8, 10, 11, 12, 17, 19, 24, 26, 27, 29, 32), "f32x3": (0, 1, 2, 3), "f32x2": (0, 1, 2, 3, 4, 8)}
+TILE_NAMES = [f"{bm}x{bn}w{w}s{st}" + ("dma" if 26 <= i <= 32 else "") + ("res" if i == 33 else "") for i, (bm, bn, w, st) in enumerate(TILES)]
 
 
 class Y3Error(RuntimeError):
@@ -101,7 +104,6 @@ SYMBOLS = {
     "y3_net_set_xcd_mode": (_i, [_vp, _i]),
     "y3_net_set_k_chunk": (_i, [_vp, _i]),
     "y3_net_set_stem_fusion": (_i, [_vp, _i]),
-    "y3_net_set_block_fusion": (_i, [_vp, _i]),
     "y3_net_measure_sclk": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _fp, _vp]),
     "y3_net_measure_sclk_conv": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _i, _fp, _vp]),
     "y3_net_measure_sclk_all": (_i, [_vp, _vp, _i, C.POINTER(_vp), _i, _fp, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),

@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["conv_f32.hip", "conv_head.hip", "conv_res_f32.hip", "conv_stem.hip", "conv_bf16.hip", "conv_res_bf16.hip", "conv_block_bf16.hip", "conv_f32x3.hip", "decode.hip", "nms.hip", "elementwise.hip", "preprocess.hip", "y3_api.cpp", "comm.cpp"]
+SOURCES = ["conv_f32.hip", "conv_head.hip", "conv_res_f32.hip", "conv_stem.hip", "conv_bf16.hip", "conv_res_bf16.hip", "conv_f32x3.hip", "decode.hip", "nms.hip", "elementwise.hip", "preprocess.hip", "y3_api.cpp", "comm.cpp"]
 OUT = os.path.join(os.path.dirname(HERE), "lib", "liby3hip.so")
 # -ffp-contract=off: epilogue / decode / IoU arithmetic must not be re-associated into FMAs (parity with the
 # reference's separate fp32 multiply and add); MFMA accumulation is unaffected.

@@ -438,21 +438,21 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
 // (profiles/r02_tile_sweep_bf16_pipelined_b128_s416.txt, r02_bf16_pipelined_tile_pmc.txt: MFMA busy 0.45 vs 0.58).
 // ---------------------------------------------------------------------------------------------------------
 // tile table of the bf16 kernel: {BM, BN, waves, BK}
+// Round 5: the table holds exactly the tiles a plan can select -- a packaged tuning table (tuning/bf16_*.json), the library's heuristic or
+// the head-decode fallback (choose_tile_bf16 / run_slice in y3_api.cpp) names every one of them (tests/test_abi.py); the other ids are retired.
 static const TileInfo kTilesBf16[BF16_TILE_COUNT] = {
-    {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 32, 4, 64},
-    {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 64},
-    {128, 128, 4, 64}, {256, 128, 8, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {64, 128, 4, 64}, {128, 256, 8, 64},  // 8..13: LDS-DMA
-    {256, 256, 8, 64}, {256, 128, 4, 64}, {128, 256, 4, 64},  // 14..16: LDS-DMA, 128x64 / 64x128 wave tiles
-    {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64},   // 17..19: LDS-DMA, 16 waves (64x64 / 64x32 / 32x64 wave tiles)
-    {0, 0, 0, 64},                                                // 20: retired id (the pipelined tile of round 2)
-    {128, 256, 8, 32}, {256, 128, 8, 32}, {128, 128, 4, 32},      // 21..23: LDS-DMA with BK = 32, several workgroups per CU
-    {256, 256, 16, 64}, {256, 128, 16, 64}, {128, 256, 16, 64}, {128, 128, 4, 64}, {128, 64, 4, 64}, {64, 128, 4, 64},  // 24..29: 16x16x32 MFMAs
-    {128, 64, 4, 32}, {64, 64, 4, 32},                            // 30, 31: LDS-DMA with BK = 32 for the Cin = 32 / Cout = 64 layer
+    {128, 128, 4, 64}, {0, 0, 0, 64}, {0, 0, 0, 64}, {64, 64, 4, 64}, {128, 32, 4, 64},
+    {128, 64, 4, 32}, {64, 64, 4, 32}, {0, 0, 0, 64},
+    {128, 128, 4, 64}, {0, 0, 0, 64}, {128, 64, 4, 64}, {64, 64, 4, 64}, {64, 128, 4, 64}, {0, 0, 0, 64},  // 8..13: LDS-DMA
+    {0, 0, 0, 64}, {0, 0, 0, 64}, {0, 0, 0, 64},                  // 14..16
+    {256, 256, 16, 64}, {0, 0, 0, 64}, {128, 256, 16, 64},        // 17..19: LDS-DMA, 16 waves (64x64 / 32x64 wave tiles)
+    {0, 0, 0, 64},                                                // 20
+    {0, 0, 0, 32}, {256, 128, 8, 32}, {0, 0, 0, 32},              // 21..23: LDS-DMA with BK = 32, two workgroups per CU
+    {256, 256, 16, 64}, {0, 0, 0, 64}, {128, 256, 16, 64}, {128, 128, 4, 64}, {0, 0, 0, 64}, {64, 128, 4, 64},  // 24..29: 16x16x32 MFMAs
+    {0, 0, 0, 32}, {0, 0, 0, 32},                                 // 30, 31
     {128, 64, 8, 32},                                             // 32: weight-resident 3x3 / stride 1, Cin = 32 / 64 (conv_res_bf16.hip): 4 x 32 pixels x 64 channels per workgroup tile
-    // 33..35 (3x3 / stride 1 with tap-row reuse: one activation tile per kernel row, taps from shifted LDS rows) and 36 (256x256 on four waves
-    // of 128x128, hand-pipelined): retired in round 5.  Both were parity-green and neutral / slower in the two-lane step and no plan selected
-    // them (profiles/r04_ab_bf16_rs.txt, r04_tile_sweep_bf16_rs_b64.txt, r04_tile_sweep_bf16_w4.txt, r04_bench_bf16_b128_s416_table_{rs,w4}.json);
-    // the code is in the history (csrc/conv_bf16_rs.hip, csrc/conv_bf16_w4.hip at commit 1777145).
+    // 33..35 (3x3 / stride 1 with tap-row reuse) and 36 (256x256 on four waves of 128x128, hand-pipelined): parity-green, neutral / slower in the
+    // two-lane step (profiles/r04_ab_bf16_rs.txt, r04_tile_sweep_bf16_w4.txt); code in the history (commit 1777145)
     {0, 0, 0, 64}, {0, 0, 0, 64}, {0, 0, 0, 64}, {0, 0, 0, 64},
 };
 
@@ -502,36 +502,21 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
     if (tile == 32) return (!out_f32 && conv_res_bf16_fits(a)) ? launch_conv_res_bf16(a, s) : hipErrorInvalidValue;
     switch (tile) {
         case 0: return launch_tb<2, 2, 2, 2, 64>(a, out_f32, s);
-        case 1: return launch_tb<2, 2, 4, 2, 64>(a, out_f32, s);
-        case 2: return launch_tb<2, 1, 2, 2, 64>(a, out_f32, s);
         case 3: return launch_tb<1, 1, 2, 2, 64>(a, out_f32, s);
         case 4: return launch_tb<1, 1, 4, 1, 64>(a, out_f32, s);
         case 5: return launch_tb<2, 1, 2, 2, 32>(a, out_f32, s);
         case 6: return launch_tb<1, 1, 2, 2, 32>(a, out_f32, s);
-        case 7: return launch_tb<1, 2, 2, 2, 64>(a, out_f32, s);
         case 8: return launch_tb<2, 2, 2, 2, 64, true>(a, out_f32, s);    // 128x128 LDS-DMA
-        case 9: return launch_tb<2, 2, 4, 2, 64, true>(a, out_f32, s);    // 256x128, 8 waves, LDS-DMA
         case 10: return launch_tb<2, 1, 2, 2, 64, true>(a, out_f32, s);   // 128x64 LDS-DMA
         case 11: return launch_tb<1, 1, 2, 2, 64, true>(a, out_f32, s);   // 64x64 LDS-DMA
         case 12: return launch_tb<1, 2, 2, 2, 64, true>(a, out_f32, s);   // 64x128 LDS-DMA
-        case 13: return launch_tb<2, 2, 2, 4, 64, true>(a, out_f32, s);   // 128x256, 8 waves, LDS-DMA
-        case 14: return launch_tb<4, 2, 2, 4, 64, true>(a, out_f32, s);   // 256x256, 8 waves (128x64 wave tile), LDS-DMA
-        case 15: return launch_tb<4, 2, 2, 2, 64, true>(a, out_f32, s);   // 256x128, 4 waves (128x64 wave tile), LDS-DMA
-        case 16: return launch_tb<2, 4, 2, 2, 64, true>(a, out_f32, s);   // 128x256, 4 waves (64x128 wave tile), LDS-DMA
         case 17: return launch_tb<2, 2, 4, 4, 64, true>(a, out_f32, s);   // 256x256, 16 waves, LDS-DMA
-        case 18: return launch_tb<2, 1, 4, 4, 64, true>(a, out_f32, s);   // 256x128, 16 waves, LDS-DMA
         case 19: return launch_tb<1, 2, 4, 4, 64, true>(a, out_f32, s);   // 128x256, 16 waves, LDS-DMA
-        case 21: return launch_tb<2, 2, 2, 4, 32, true, 4>(a, out_f32, s);   // 128x256, 8 waves, BK 32, two workgroups per CU
         case 22: return launch_tb<2, 2, 4, 2, 32, true, 4>(a, out_f32, s);   // 256x128, 8 waves, BK 32, two workgroups per CU
-        case 23: return launch_tb<2, 2, 2, 2, 32, true, 4>(a, out_f32, s);   // 128x128, 4 waves, BK 32: up to four workgroups per CU
         case 24: return launch_tb<2, 2, 4, 4, 64, true, 1, true>(a, out_f32, s);   // tile 17 on 16x16x32 MFMAs
-        case 25: return launch_tb<2, 1, 4, 4, 64, true, 1, true>(a, out_f32, s);   // tile 18 on 16x16x32
         case 26: return launch_tb<1, 2, 4, 4, 64, true, 1, true>(a, out_f32, s);   // tile 19 on 16x16x32
         case 27: return launch_tb<2, 2, 2, 2, 64, true, 1, true>(a, out_f32, s);   // tile 8 (128x128, 4 waves) on 16x16x32
-        case 28: return launch_tb<2, 1, 2, 2, 64, true, 1, true>(a, out_f32, s);   // tile 10 (128x64, 4 waves) on 16x16x32
         case 29: return launch_tb<1, 2, 2, 2, 64, true, 1, true>(a, out_f32, s);   // tile 12 (64x128, 4 waves) on 16x16x32
-        case 30: return launch_tb<2, 1, 2, 2, 32, true>(a, out_f32, s);      // 128x64, 4 waves, BK 32, LDS-DMA (tile 5 without the VGPR round trip)
-        case 31: return launch_tb<1, 1, 2, 2, 32, true>(a, out_f32, s);      // 64x64, 4 waves, BK 32, LDS-DMA
         default: return hipErrorInvalidValue;
     }
 }

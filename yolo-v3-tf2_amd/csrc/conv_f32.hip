@@ -460,18 +460,21 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_f32_mfma(const ConvAr
 
 // tile table: {BM, BN, waves, LDS stages}; ids are stable (tuning files refer to them).  Ids 20..22 and 25 were the
 // timing-only probes of rounds 1-2 (removed in round 4; the ids stay reserved), 33..45 the stream-K / residual-prefetch tiles.
+// Round 5: the table holds exactly the tiles a plan can select -- a packaged tuning table (tuning/f32_*.json) or the library's heuristic
+// (choose_tile in y3_api.cpp) names every one of them (tests/test_abi.py).  The other ids of rounds 1-4 (two-stage forms of 0..5, the 8- and
+// 16-wave 128x128 / 256x128 tiles, the register-budget variant 24, the two-stage LDS-DMA tiles 28..30, the ablations 20..22, 25) are retired:
+// {0,0,0,0}, y3_tile_built answers 0; the kernel template itself is general and the sweeps that retired them are under profiles/.
 static const TileInfo kTiles[TILE_COUNT] = {
-    {128, 128, 4, 2}, {256, 64, 4, 2}, {256, 32, 4, 2}, {128, 64, 4, 2}, {64, 128, 4, 2}, {64, 64, 4, 2},
-    {128, 128, 4, 1}, {256, 64, 4, 1}, {256, 32, 4, 1}, {128, 64, 4, 1}, {64, 128, 4, 1}, {64, 64, 4, 1},
-    {128, 128, 8, 1}, {128, 128, 8, 2}, {128, 128, 16, 1}, {128, 128, 16, 2},
-    {256, 128, 16, 1}, {128, 64, 8, 1}, {256, 64, 8, 1}, {128, 64, 8, 2},
-    {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},            // 20..22: retired ids
-    {128, 128, 4, 1}, {128, 128, 4, 1},                  // 128x128 with the register budget of 3 / 4 waves per SIMD
-    {0, 0, 0, 0},                                        // 25: retired id
-    {64, 128, 4, 2}, {64, 64, 4, 2}, {128, 128, 4, 2}, {128, 64, 4, 2}, {256, 32, 4, 2},  // 26..30: LDS-DMA loads
+    {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},                                  // 0..5
+    {128, 128, 4, 1}, {0, 0, 0, 0}, {256, 32, 4, 1}, {128, 64, 4, 1}, {64, 128, 4, 1}, {64, 64, 4, 1},                 // 6..11: single LDS stage
+    {128, 128, 8, 1}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},                                                          // 12..15
+    {0, 0, 0, 0}, {128, 64, 8, 1}, {0, 0, 0, 0}, {0, 0, 0, 0},                                                           // 16..19
+    {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},                                                                            // 20..22
+    {128, 128, 4, 1}, {0, 0, 0, 0},                      // 23: 128x128 with the register budget of 3 waves per SIMD
+    {0, 0, 0, 0},                                        // 25
+    {64, 128, 4, 2}, {64, 64, 4, 2}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},   // 26, 27: LDS-DMA loads, two stages
     {64, 128, 4, 1}, {64, 64, 4, 1},                     // 31, 32: LDS-DMA, single stage
     {128, 64, 8, 2},                                     // 33: weight-resident 3x3 / stride 1 / Cin = 32 (conv_res_f32.hip): 8 x 16 pixels x 64 channels per workgroup tile
-    {32, 128, 4, 1},                                     // 34: 32x128 (one row of four waves), LDS-DMA, single stage: twice the pixel tiles of 64x128 for the 13^2 / 26^2 1x1 layers (VERDICT r04 #3b)
 };
 
 #ifdef Y3_PHASE_STAMPS
@@ -508,45 +511,33 @@ static hipError_t launch_k(const ConvArgs &a_in, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int TM, int TN, int WR, int WC, int MINW1 = 1>
-static hipError_t launch_t(const ConvArgs &a, int stages, hipStream_t s)
+// single LDS stage, register-staged operand loads.  MINW: register budget (waves per SIMD) -- with 4, the two accumulators of the 32x64 wave
+// tile stay in architectural VGPRs and the epilogue needs no v_accvgpr_read (nor the prologue 32-64 v_accvgpr_write: with the SIMD full of
+// 64-cycle MFMAs every vector instruction outside the K loop waits ~one MFMA for its issue slot, profiles/r03_ab_f32_prologue.txt)
+template <int TM, int TN, int WR, int WC, int MINW = 1>
+static hipError_t launch_s1(const ConvArgs &a, hipStream_t s)
 {
-    // MINW1: register budget (waves per SIMD) of the single-stage variant -- with 4, the two accumulators of the
-    // 32x64 wave tile stay in architectural VGPRs and the epilogue needs no v_accvgpr_read (nor the prologue 32-64
-    // v_accvgpr_write: with the SIMD full of 64-cycle MFMAs every vector instruction outside the K loop waits ~one MFMA for
-    // its issue slot, profiles/r03_ab_f32_prologue.txt).  The LDS-DMA tiles 26, 27, 31, 32 and the 64x64 tiles pass 4 as well.
-    if (a.src1) return stages == 2 ? launch_k<TM, TN, WR, WC, true, 2>(a, s) : launch_k<TM, TN, WR, WC, true, 1, MINW1>(a, s);
-    return stages == 2 ? launch_k<TM, TN, WR, WC, false, 2>(a, s) : launch_k<TM, TN, WR, WC, false, 1, MINW1>(a, s);
+    return a.src1 ? launch_k<TM, TN, WR, WC, true, 1, MINW>(a, s) : launch_k<TM, TN, WR, WC, false, 1, MINW>(a, s);
 }
 
 hipError_t launch_conv_f32(const ConvArgs &a, int tile, hipStream_t s)
 {
     if (!conv_tile_built(tile)) return hipErrorInvalidValue;
     if (tile == 33) return conv_res_f32_fits(a) ? launch_conv_res_f32(a, s) : hipErrorInvalidValue;
-    const int stages = kTiles[tile].stages;
     switch (tile) {
-        case 0: case 6: return launch_t<2, 2, 2, 2>(a, stages, s);    // 128x128, 4 waves
-        case 1: case 7: return launch_t<2, 2, 4, 1>(a, stages, s);    // 256x64
-        case 2: case 8: return launch_t<2, 1, 4, 1>(a, stages, s);    // 256x32
-        case 3: case 9: return launch_t<1, 2, 4, 1, 4>(a, stages, s);    // 128x64
-        case 4: case 10: return launch_t<1, 2, 2, 2, 4>(a, stages, s);   // 64x128
-        case 5: case 11: return launch_t<1, 1, 2, 2, 4>(a, stages, s);   // 64x64
-        case 12: case 13: return launch_t<2, 1, 2, 4>(a, stages, s);  // 128x128, 8 waves
-        case 14: case 15: return launch_t<1, 1, 4, 4>(a, stages, s);  // 128x128, 16 waves
-        case 16: return launch_t<2, 1, 4, 4>(a, stages, s);           // 256x128, 16 waves
-        case 17: case 19: return launch_t<1, 1, 4, 2>(a, stages, s);  // 128x64, 8 waves
-        case 18: return launch_t<2, 1, 4, 2>(a, stages, s);           // 256x64, 8 waves
-        // direct-to-LDS operand loads, double buffered
-        case 26: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 4, 1>(a, s);  // 64x128
-        case 27: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 4, 1>(a, s);  // 64x64
-        case 28: return a.src1 ? launch_k<2, 2, 2, 2, true, 2, 1, 1>(a, s) : launch_k<2, 2, 2, 2, false, 2, 1, 1>(a, s);  // 128x128
-        case 29: return a.src1 ? launch_k<1, 2, 4, 1, true, 2, 1, 1>(a, s) : launch_k<1, 2, 4, 1, false, 2, 1, 1>(a, s);  // 128x64
-        case 30: return a.src1 ? launch_k<2, 1, 4, 1, true, 2, 1, 1>(a, s) : launch_k<2, 1, 4, 1, false, 2, 1, 1>(a, s);  // 256x32
+        case 6: return launch_s1<2, 2, 2, 2>(a, s);        // 128x128, 4 waves
+        case 8: return launch_s1<2, 1, 4, 1>(a, s);        // 256x32
+        case 9: return launch_s1<1, 2, 4, 1, 4>(a, s);     // 128x64
+        case 10: return launch_s1<1, 2, 2, 2, 4>(a, s);    // 64x128
+        case 11: return launch_s1<1, 1, 2, 2, 4>(a, s);    // 64x64
+        case 12: return launch_s1<2, 1, 2, 4>(a, s);       // 128x128, 8 waves
+        case 17: return launch_s1<1, 1, 4, 2>(a, s);       // 128x64, 8 waves
+        case 23: return launch_s1<2, 2, 2, 2, 3>(a, s);    // 128x128 within 3 waves per SIMD of registers
+        // direct-to-LDS operand loads
+        case 26: return a.src1 ? launch_k<1, 2, 2, 2, true, 2, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 2, 4, 1>(a, s);  // 64x128, two stages
+        case 27: return a.src1 ? launch_k<1, 1, 2, 2, true, 2, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 2, 4, 1>(a, s);  // 64x64, two stages
         case 31: return a.src1 ? launch_k<1, 2, 2, 2, true, 1, 4, 1>(a, s) : launch_k<1, 2, 2, 2, false, 1, 4, 1>(a, s);  // 64x128, 1 stage
         case 32: return a.src1 ? launch_k<1, 1, 2, 2, true, 1, 4, 1>(a, s) : launch_k<1, 1, 2, 2, false, 1, 4, 1>(a, s);  // 64x64, 1 stage
-        case 34: return a.src1 ? launch_k<1, 1, 1, 4, true, 1, 4, 1>(a, s) : launch_k<1, 1, 1, 4, false, 1, 4, 1>(a, s);  // 32x128, 1 stage
-        case 23: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 3>(a, s) : launch_k<2, 2, 2, 2, false, 1, 3>(a, s);
-        case 24: return a.src1 ? launch_k<2, 2, 2, 2, true, 1, 4>(a, s) : launch_k<2, 2, 2, 2, false, 1, 4>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -483,18 +483,21 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_f32x3_mfma(const ConvArgs p
 }
 
 // tile table: {BM, BN, waves, BK}
+// Round 5: only the tiles a plan can select are instantiated (tuning/f32x3_*.json, f32x2_*.json, choose_tile_x3 / choose_tile_x2 in
+// y3_api.cpp; tests/test_abi.py); the schedule variants of rounds 1-2 (BK 16 / 64, interleaved / pinned DMA issue, three stages) are retired.
 static const TileInfo kTilesX3[X3_TILE_COUNT] = {
-    {128, 128, 4, 32}, {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 32}, {256, 128, 8, 32}, {256, 64, 4, 32},
-    {128, 64, 4, 64}, {64, 64, 4, 64}, {128, 256, 8, 32},
-    {128, 128, 4, 32}, {256, 128, 8, 32}, {128, 256, 8, 32}, {128, 128, 8, 32}, {128, 64, 4, 32}, {64, 128, 4, 32}, {64, 64, 4, 32},
-    {256, 256, 8, 16}, {256, 128, 8, 16}, {128, 256, 8, 16}, {128, 128, 4, 16},
-    {256, 128, 8, 32}, {128, 256, 8, 32}, {128, 128, 4, 32}, {128, 128, 8, 32},   // 20..23: interleaved DMA issue
-    {256, 128, 8, 32}, {128, 256, 8, 32},                                         // 24..25: + pinned order
-    {256, 128, 16, 32}, {128, 256, 16, 32},                                       // 26..27: 16 waves, 64x32 wave tiles
-    {0, 0, 0, 32}, {0, 0, 0, 32},                                                 // 28..29: retired ids (timing probes of round 1)
-    {128, 128, 8, 32}, {256, 128, 16, 32}, {256, 128, 8, 32}, {128, 256, 16, 32},  // 30..33: three LDS stages
+    {128, 128, 4, 32}, {128, 64, 4, 32}, {64, 64, 4, 32}, {64, 128, 4, 32}, {256, 128, 8, 32}, {0, 0, 0, 32},
+    {0, 0, 0, 64}, {0, 0, 0, 64}, {128, 256, 8, 32},
+    {128, 128, 4, 32}, {0, 0, 0, 32}, {0, 0, 0, 32}, {128, 128, 8, 32}, {128, 64, 4, 32}, {64, 128, 4, 32}, {0, 0, 0, 32},   // 9, 13, 14: single LDS stage
+    {0, 0, 0, 16}, {0, 0, 0, 16}, {0, 0, 0, 16}, {0, 0, 0, 16},
+    {0, 0, 0, 32}, {0, 0, 0, 32}, {0, 0, 0, 32}, {0, 0, 0, 32},
+    {0, 0, 0, 32}, {0, 0, 0, 32},
+    {256, 128, 16, 32}, {128, 256, 16, 32},                                       // 26..27: 16 waves, 64x32 wave tiles (two-plane mode)
+    {0, 0, 0, 32}, {0, 0, 0, 32},
+    {0, 0, 0, 32}, {0, 0, 0, 32}, {0, 0, 0, 32}, {0, 0, 0, 32},
 };
 
+bool conv_x3_tile_built(int tile);
 TileInfo conv_x3_tile_info(int tile) { return kTilesX3[(tile >= 0 && tile < X3_TILE_COUNT) ? tile : 0]; }
 
 template <int NPL, int TM, int TN, int WR, int WC, int BK, bool CONCAT, bool OUT_F32, int STAGES = 2, int VAR = V_BURST>
@@ -533,7 +536,7 @@ hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStrea
 {
     if (tile < 0 || tile >= X3_TILE_COUNT) return hipErrorInvalidValue;
     const TileInfo t = kTilesX3[tile];
-    if (t.bm == 0) return hipErrorInvalidValue;   // retired id
+    if (t.bm == 0 || !conv_x3_tile_built(tile)) return hipErrorInvalidValue;   // retired id / two-plane only
     if (a.Cin % t.stages || a.CoutPad % t.bn || (a.src1 && a.C0 % t.stages)) return hipErrorInvalidValue;  // .stages holds BK
     switch (tile) {
         case 0: return launch_tx<2, 2, 2, 2, 32>(a, out_f32, s);
@@ -541,30 +544,11 @@ hipError_t launch_conv_f32x3(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 2: return launch_tx<1, 1, 2, 2, 32>(a, out_f32, s);
         case 3: return launch_tx<1, 2, 2, 2, 32>(a, out_f32, s);
         case 4: return launch_tx<2, 2, 4, 2, 32>(a, out_f32, s);
-        case 5: return launch_tx<2, 2, 4, 1, 32>(a, out_f32, s);
-        case 6: return launch_tx<2, 1, 2, 2, 64>(a, out_f32, s);
-        case 7: return launch_tx<1, 1, 2, 2, 64>(a, out_f32, s);
         case 8: return launch_tx<2, 2, 2, 4, 32>(a, out_f32, s);
         case 9: return launch_tx<2, 2, 2, 2, 32, 1>(a, out_f32, s);    // 128x128 w4, single stage (3 workgroups / CU)
-        case 10: return launch_tx<2, 2, 4, 2, 32, 1>(a, out_f32, s);   // 256x128 w8, single stage (2 / CU)
-        case 11: return launch_tx<2, 2, 2, 4, 32, 1>(a, out_f32, s);   // 128x256 w8, single stage
         case 12: return launch_tx<2, 1, 2, 4, 32>(a, out_f32, s);      // 128x128 w8 (64x32 wave tile)
         case 13: return launch_tx<2, 1, 2, 2, 32, 1>(a, out_f32, s);   // 128x64 w4, single stage
         case 14: return launch_tx<1, 2, 2, 2, 32, 1>(a, out_f32, s);   // 64x128 w4, single stage
-        case 15: return launch_tx<1, 1, 2, 2, 32, 1>(a, out_f32, s);   // 64x64 w4, single stage
-        case 16: return launch_tx<4, 2, 2, 4, 16>(a, out_f32, s);      // 256x256 w8 (128x64 wave tile), BK 16
-        case 17: return launch_tx<2, 2, 4, 2, 16>(a, out_f32, s);      // 256x128 w8, BK 16 (2 workgroups / CU)
-        case 18: return launch_tx<2, 2, 2, 4, 16>(a, out_f32, s);      // 128x256 w8, BK 16
-        case 19: return launch_tx<2, 2, 2, 2, 16>(a, out_f32, s);      // 128x128 w4, BK 16 (3 workgroups / CU)
-        case 20: return launch_tx<2, 2, 4, 2, 32, 2, V_ILV>(a, out_f32, s);   // 256x128 w8, DMA issue interleaved with MFMA groups
-        case 21: return launch_tx<2, 2, 2, 4, 32, 2, V_ILV>(a, out_f32, s);   // 128x256 w8, interleaved
-        case 22: return launch_tx<2, 2, 2, 2, 32, 2, V_ILV>(a, out_f32, s);   // 128x128 w4, interleaved
-        case 23: return launch_tx<2, 1, 2, 4, 32, 2, V_ILV>(a, out_f32, s);   // 128x128 w8, interleaved
-        case 24: return launch_tx<2, 2, 4, 2, 32, 2, V_ILV_PINNED>(a, out_f32, s);   // 256x128 w8, interleaved + pinned issue order
-        case 25: return launch_tx<2, 2, 2, 4, 32, 2, V_ILV_PINNED>(a, out_f32, s);   // 128x256 w8, interleaved + pinned
-        case 26: return launch_tx<2, 1, 4, 4, 32>(a, out_f32, s);         // 256x128 w16 (64x32 wave tile)
-        case 27: return launch_tx<2, 1, 2, 8, 32>(a, out_f32, s);         // 128x256 w16
-        case 30: return launch_tx<2, 1, 2, 4, 32, 3>(a, out_f32, s);      // 128x128 w8, three stages
         default: return hipErrorInvalidValue;
     }
 }
@@ -582,27 +566,26 @@ hipError_t launch_conv_f32x2(const ConvArgs &a, int tile, bool out_f32, hipStrea
         case 2: return launch_tp<2, 1, 1, 2, 2, 32>(a, out_f32, s);       // 64x64 w4
         case 3: return launch_tp<2, 1, 2, 2, 2, 32>(a, out_f32, s);       // 64x128 w4
         case 4: return launch_tp<2, 2, 2, 4, 2, 32>(a, out_f32, s);       // 256x128 w8
-        case 6: return launch_tp<2, 2, 1, 2, 2, 64>(a, out_f32, s);       // 128x64 w4, BK 64
         case 8: return launch_tp<2, 2, 2, 2, 4, 32>(a, out_f32, s);       // 128x256 w8
-        case 9: return launch_tp<2, 2, 2, 2, 2, 32, 1>(a, out_f32, s);    // 128x128 w4, single stage
-        case 10: return launch_tp<2, 2, 2, 4, 2, 32, 1>(a, out_f32, s);   // 256x128 w8, single stage
         case 12: return launch_tp<2, 2, 1, 2, 4, 32>(a, out_f32, s);      // 128x128 w8
         case 26: return launch_tp<2, 2, 1, 4, 4, 32>(a, out_f32, s);      // 256x128 w16
         case 27: return launch_tp<2, 2, 1, 2, 8, 32>(a, out_f32, s);      // 128x256 w16
-        case 30: return launch_tp<2, 2, 1, 2, 4, 32, 3>(a, out_f32, s);      // 128x128 w8, three stages
-        case 31: return launch_tp<2, 2, 1, 4, 4, 32, 3>(a, out_f32, s);      // 256x128 w16, three stages
-        case 32: return launch_tp<2, 2, 2, 4, 2, 32, 3>(a, out_f32, s);      // 256x128 w8, three stages
-        case 33: return launch_tp<2, 2, 1, 2, 8, 32, 3>(a, out_f32, s);      // 128x256 w16, three stages
         default: return hipErrorInvalidValue;
     }
 }
 
-bool conv_x3_tile_built(int tile) { return (tile >= 0 && tile <= 27) || tile == 30; }
+bool conv_x3_tile_built(int tile)
+{
+    switch (tile) {
+        case 0: case 1: case 2: case 3: case 4: case 8: case 9: case 12: case 13: case 14: return true;
+        default: return false;
+    }
+}
 
 bool conv_x2_tile_built(int tile)
 {
     switch (tile) {
-        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 10: case 12: case 26: case 27: case 30: case 31: case 32: case 33: return true;
+        case 0: case 1: case 2: case 3: case 4: case 8: case 12: case 26: case 27: return true;
         default: return false;
     }
 }

@@ -160,8 +160,6 @@ struct y3_net {
     // y3_net_forward_decode: while set, the three head convs decode their own tiles into these buffers (per scale: first box
     // index, grid size, anchors) instead of writing grids.  Null outside that call.
     const y3::DecodeHead *fuse = nullptr;   // [3], in output order
-    int block_mode = 1;            // y3_net_set_block_fusion: 1 = the early residual blocks of a bf16 plan (1x1 Cx -> Cx / 2, 3x3 Cx / 2 -> Cx + shortcut, Cx = 64 / 128) run as ONE launch (csrc/conv_block_bf16.hip)
-    bool block_mode_set = false;   // y3_net_set_block_fusion was called (the Y3_BLOCK_FUSION tool override then stays out)
     int stem_mode = 1;             // y3_net_set_stem_fusion: 1 = conv0 + conv1 (+ the 1x1 after them) as one kernel when the graph allows it; 2 = conv0 + conv1 only
     bool stem_mode_set = false;    // y3_net_set_stem_fusion was called (the Y3_STEM_MODE tool override then stays out)
     bool stem_fused = false;       // (at plan time) the first two convs run as the fused stem kernel
@@ -422,35 +420,6 @@ static bool stem_conv2_applicable(const y3_net *net)
         if (net->outputs[k] == c.dst) return false;
     return true;
 }
-
-// Ops oi (conv B: 1x1) and oi + 1 (conv A: 3x3 + shortcut) of a bf16 plan form an early residual block that runs as ONE launch
-// (csrc/conv_block_bf16.hip): B = 1x1 / stride 1, Cx -> Cx / 2 with Cx = 64 or 128, A = 3x3 / stride 1, Cx / 2 -> Cx, reading only B's output and
-// adding B's input as its shortcut; nobody else reads B's output (the fused launch never writes it).  Reference: config/models/yolov3/backbone.yaml
-// (the block at 208 x 208 and the two at 104 x 104) -> core/parse_model.py:27-52, :143-160.  A property of the graph and the plan only.
-static bool block_pair_graph(const y3_net *net, int oi)
-{
-    if (net->dtype != Y3_DTYPE_BF16 || net->keep_all || oi < 0 || oi + 1 >= (int)net->ops.size()) return false;
-    if (net->ops[oi].kind != 0 || net->ops[oi + 1].kind != 0) return false;
-    const ConvSlot &B = net->convs[net->ops[oi].index], &A = net->convs[net->ops[oi + 1].index];
-    const y3_conv_desc &b = B.d, &a = A.d;
-    if (B.first_layer || b.size != 1 || b.stride != 1 || b.src1 >= 0 || b.residual >= 0 || (b.cin != 64 && b.cin != 128) || b.cout * 2 != b.cin) return false;
-    if (a.size != 3 || a.stride != 1 || a.src1 >= 0 || a.cin != b.cout || a.cout != b.cin || A.cout_pad != a.cout || a.src0 != b.dst || a.residual != b.src0) return false;
-    if (b.src0 == net->input_tensor) return false;      // (the image batch may be fp32 / caller-owned: the patch reader wants an arena tensor in bf16)
-    for (int k = 0; k < 3; ++k)
-        if (net->outputs[k] == b.dst || net->outputs[k] == b.src0) return false;
-    for (size_t i = 0; i < net->ops.size(); ++i) {      // B's output has no other reader
-        if ((int)i == oi + 1) continue;
-        if (net->ops[i].kind == 0) {
-            const y3_conv_desc &d = net->convs[net->ops[i].index].d;
-            if (d.src0 == b.dst || d.src1 == b.dst || d.residual == b.dst) return false;
-        } else {
-            const y3_aux_desc &x = net->aux[net->ops[i].index];
-            if (x.src0 == b.dst || x.src1 == b.dst) return false;
-        }
-    }
-    return true;
-}
-static bool block_pair(const y3_net *net, int oi) { return net->block_mode && net->early_ops == 0 && block_pair_graph(net, oi); }
 
 // Does this conv's launch write an fp32 net output directly (bf16 / plane-split plans)?  Mirrors the `staged` rule of y3_net_plan: an
 // output that another op reads, or that a shortcut / first-layer conv writes, stays in the arena in the mode's format instead.
@@ -759,22 +728,11 @@ try {
     // takes effect at once on a planned net when the graph qualifies (decided again by the next y3_net_plan)
     if (net->image_size) {
         net->stem_fused = on && stem_applicable(net);
-        net->stem_conv2 = net->stem_fused && on == 1 && stem_conv2_applicable(net) && !block_pair(net, 2);
+        net->stem_conv2 = net->stem_fused && on == 1 && stem_conv2_applicable(net);
     }
     return Y3_OK;
 }
 Y3_CATCH("y3_net_set_stem_fusion")
-
-y3_status y3_net_set_block_fusion(y3_net *net, int on)
-try {
-    if (!net || on < 0 || on > 1) return fail(Y3_ERR_INVALID, "y3_net_set_block_fusion: argument must be 0 or 1");
-    net->block_mode = on;
-    net->block_mode_set = true;
-    if (net->image_size)   // a planned net: the stem hands the 1x1 behind it to the first block's launch, or takes it back
-        net->stem_conv2 = net->stem_fused && net->stem_mode == 1 && stem_conv2_applicable(net) && !block_pair(net, 2);
-    return Y3_OK;
-}
-Y3_CATCH("y3_net_set_block_fusion")
 
 y3_status y3_net_set_k_chunk(y3_net *net, int channels)
 try {
@@ -937,12 +895,7 @@ try {
         if (env >= 0 && env <= 2 && !net->stem_mode_set) net->stem_mode = env;
     }
     net->stem_fused = net->stem_mode && stem_applicable(net);
-    {   // Y3_BLOCK_FUSION (tools: same-process-tree A/B): overrides the default, not an explicit setter call
-        static const int env = [] { const char *e = getenv("Y3_BLOCK_FUSION"); return e ? atoi(e) : -1; }();
-        if (env >= 0 && env <= 1 && !net->block_mode_set) net->block_mode = env;
-    }
-    // the 1x1 behind the stem (backbone.yaml layer 3) belongs to the first residual block: when that block runs as one launch, the stem leaves it alone
-    net->stem_conv2 = net->stem_fused && net->stem_mode == 1 && stem_conv2_applicable(net) && !block_pair(net, 2);
+    net->stem_conv2 = net->stem_fused && net->stem_mode == 1 && stem_conv2_applicable(net);
     if (net->nclasses > 0) {   // scratch of y3_net_detect: no allocation inside the stream-ordered call
         size_t off[9], n_boxes, gelems[3];
         int32_t gs[3];
@@ -1089,30 +1042,9 @@ static y3_status run_slice(y3_net *net, const float *images, float *const grids[
                 if (ms_out && o.index < n_ms) ms_out[o.index] = 0.0f;
                 continue;
             }
-            // early residual block as one launch (bf16): the 1x1 has no launch of its own, the 3x3's launch computes it from the block input's patch
-            auto block_tile32 = [&](int op_a) {     // does the block's 3x3 take the weight-resident kernel family (tile 32: from its shape alone)?
-                const ConvSlot &ca = net->convs[net->ops[op_a].index];
-                const long long ho = net->image_size / ca.d.out_div;
-                return (ca.tile_bf16 >= 0 ? ca.tile_bf16 : choose_tile_bf16(ca, (long long)nb * ho * ho, (long long)net->max_batch * ho * ho, true)) == 32;
-            };
-            if (bf && block_pair(net, oi) && block_tile32(oi + 1)) {
-                if (ms_out && o.index < n_ms) ms_out[o.index] = 0.0f;
-                continue;
-            }
-            const bool block_here = bf && oi > 0 && block_pair(net, oi - 1) && block_tile32(oi);
             if (ms_out) HIP_TRY(hipEventRecord(ev0, s));
             hipError_t e;
-            if (block_here) {
-                const ConvSlot &cb = net->convs[net->ops[oi - 1].index];
-                a.wpk = c.wbf_dev;
-                a.w_bytes = (unsigned)((size_t)c.cout_pad * c.K * 2);
-                a.blk.w = cb.wbf_dev;
-                a.blk.scale = cb.scale_dev;
-                a.blk.shift = cb.shift_dev;
-                a.blk.leaky = cb.d.leaky;
-                if (!a.residual || !a.blk.w || !y3::conv_block_bf16_fits(a)) return fail(Y3_ERR_STATE, "conv %d: the fused residual block does not fit", o.index);
-                e = y3::launch_conv_block_bf16(a, s);
-            } else if (net->stem_fused && oi == 1) {
+            if (net->stem_fused && oi == 1) {
                 const ConvSlot &c0 = net->convs[net->ops[0].index];
                 y3::StemArgs sa{};
                 sa.img = static_cast<const float *>(ptr(c0.d.src0));

@@ -8,14 +8,6 @@
 
 namespace y3 {
 
-// The 1x1 conv in FRONT of a 3x3 + shortcut conv, when both run as one launch (a whole residual block: conv_block_bf16.hip).  w == nullptr: none.
-struct BlockHead {
-    const void *w;         // packed [Cin of the 3x3][channels of the block input] bf16, k = c
-    const float *scale;    // [Cin of the 3x3]
-    const float *shift;
-    int leaky;
-};
-
 // One fused conv launch: Conv2D [+BN] [+LeakyReLU(0.1)] [+shortcut add], optional
 // (nearest-x2-upsampled src0) (+) src1 channel concat in the A-operand gather.
 struct ConvArgs {
@@ -48,7 +40,6 @@ struct ConvArgs {
     unsigned long long *clk_stamps;   // [4]
     int n_cus;             // compute units of the net's device, read once by y3_net_plan: sizes the grids of the persistent kernels (conv_res_*.hip)
     int device;            // the net's device index (the launch goes there: Y3_ENTER_DEVICE); -1 = not known, launchers ask the runtime
-    BlockHead blk;         // conv_block_bf16.hip only: the block's 1x1 conv; `residual` is then the block's input (read once, as a patch)
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to the
@@ -67,7 +58,7 @@ inline hipError_t set_max_lds_once(LdsAttrOnce &st, const void *fn, int bytes, i
 }
 
 // tile configurations of the fp32 MFMA kernel (index into the table in conv_f32.hip)
-static constexpr int TILE_COUNT = 35;  // 20..22, 25: retired ids (the timing-only probes of rounds 1-2); 33: the weight-resident 3x3 kernel (conv_res_f32.hip)
+static constexpr int TILE_COUNT = 34;  // 33: the weight-resident 3x3 kernel (conv_res_f32.hip); ids without a selecting plan are retired (conv_f32.hip)
 struct TileInfo { int bm, bn, waves, stages; };
 TileInfo conv_tile_info(int tile);
 bool conv_tile_built(int tile);        // false: retired id
@@ -122,9 +113,6 @@ hipError_t launch_conv_bf16(const ConvArgs &a, int tile, bool out_f32, hipStream
 // weight-resident 3x3 / stride-1 conv for Cin = 32 / 64 (conv_res_bf16.hip): the early short-K layers of the bf16 path
 bool conv_res_bf16_fits(const ConvArgs &a);
 hipError_t launch_conv_res_bf16(const ConvArgs &a, hipStream_t s);
-// a whole early residual block (1x1 Cx -> Cx / 2, then 3x3 Cx / 2 -> Cx + shortcut; Cx = 64 / 128) in one launch (conv_block_bf16.hip)
-bool conv_block_bf16_fits(const ConvArgs &a);
-hipError_t launch_conv_block_bf16(const ConvArgs &a, hipStream_t s);
 hipError_t launch_conv_first_bf16(const ConvArgs &a, const float *w_hwio_dev, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void *x, float *y, size_t n, hipStream_t s);
 
