@@ -1222,21 +1222,14 @@ static y3_status run(y3_net *net, const float *images, int batch, float *const g
         // tools/timeline_dump.py shows lane 0 four kernels ahead), and a start offset between the lanes only costs
         // (profiles/r03_ab_lane_stagger.txt).  A captured forward replays with both branches released at once either way.
         const int n_ops = (int)net->ops.size();
-        // Y3_LANE_STAGGER=k (tools: VERDICT r04 #3a): lane l starts when lane l - 1 is k ops into the list (a stream wait on an event
-        // recorded behind that op), so that one lane's short 1x1 launches run beside the other lane's 3x3 K loops.  0 / unset: both
-        // lanes released at once (what ships; profiles/r03_ab_lane_stagger.txt, r05_ab_f32_lane_stagger.txt)
-        static const int stagger = [] { const char *e = getenv("Y3_LANE_STAGGER"); return e ? atoi(e) : 0; }();
-        const int k = (stagger > 0 && stagger < n_ops) ? stagger : 0;
-        for (int oi = 0; oi < n_ops + k * (lanes - 1); ++oi)
+        // (A start offset between the lanes was measured again in round 5 for the fp32 plan -- lane 1 released 1 / 2 / 4 ops behind lane 0: at most
+        // +0.28 %, inside the process-to-process spread, profiles/r05_ab_f32_lane_stagger.txt; not kept.)
+        for (int oi = 0; oi < n_ops; ++oi)
             for (int l = 0; l < lanes; ++l) {
                 const int nb = start[l + 1] - start[l];
-                const int op = oi - k * l;
-                if (nb <= 0 || op < 0 || op >= n_ops) continue;
-                if (k && l > 0 && op == 0) HIP_TRY(hipStreamWaitEvent(net->lane_stream[l], net->join_ev[l - 1], 0));
-                y3_status st = run_slice(net, images, grids, start[l], nb, net->lane_stream[l], nullptr, 0, l, lanes, op, op + 1);
+                if (nb <= 0) continue;
+                y3_status st = run_slice(net, images, grids, start[l], nb, net->lane_stream[l], nullptr, 0, l, lanes, oi, oi + 1);
                 if (st != Y3_OK) return st;
-                // (join_ev[l] is re-recorded at the end of the lane below: an event names its latest record only for waits enqueued after it)
-                if (k && l + 1 < lanes && op == k - 1) HIP_TRY(hipEventRecord(net->join_ev[l], net->lane_stream[l]));
             }
     }
     for (int l = 0; l < lanes; ++l) {
