@@ -41,18 +41,6 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 // Same LDS image, same bytes read per K tile, same MFMA cycles per FLOP; the chip holds a higher clock on this shape
 // (MI355X_MICROARCH.md "DVFS give-back" item 7: 1.12-1.15 x the FLOP/s on random data).  Fragment: lane l holds k = 8 (l >> 4) ..
 // + 7 of row l & 15; C: acc[mb][nb][j] = row 16 mb + 4 (l >> 4) + j, column 16 nb + (l & 15).
-// Direct epilogue of the 16x16x32 tiles with 64-channel wave tiles (round 5; Y3_BF16_DIRECT_EPILOGUE=0 builds the LDS-transposed form for A/Bs).
-// In the 16x16x32 accumulator layout lane (c = l & 15) of block nb holds column 16 nb + c of the wave's 64: four columns per lane, 16 apart.  The
-// weight rows of a wave's 64 output channels are therefore fetched PERMUTED -- LDS row 16 nb + c receives channel 4 c + nb (one address computed in
-// the prologue; the K loop and the LDS image are untouched) -- so that a lane's four columns are four CONSECUTIVE channels: 8 bytes of one pixel,
-// the 16 lanes of a row group one whole 128-byte line, a wave store instruction four whole lines.  No transposition through LDS: that round
-// trip moved 2 x 256 KB per 256x256 tile through the one LDS of the CU -- ds_write_b32 at 64 B/clk + 2-way conflicting ds_read_b128 = ~6000 cycles
-// = 3 us of the 3-5 us epilogue (SQ_LDS_BANK_CONFLICT was a third of SQ_ACTIVE_INST_LDS in profiles/r05_bf16_pmc.txt).  Same arithmetic per
-// element, same rounding: bit-identical outputs.
-#ifndef Y3_BF16_DIRECT_EPILOGUE
-#define Y3_BF16_DIRECT_EPILOGUE 1
-#endif
-
 #ifdef Y3_PHASE_STAMPS
 // Diagnostic build only (csrc/build.py --variant ... -DY3_PHASE_STAMPS, tools/phase_stamps.py): thread 0 of every workgroup of the
 // launches whose K equals y3_dbg_sel_k stores s_memrealtime (100 MHz) at kernel entry, before the first fetch, after the first
@@ -89,7 +77,6 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
     constexpr int ROWB = DMA ? 2 * BK : 2 * BK + 16;  // LDS row bytes
     constexpr int STAGE_B = (BM + BN) * ROWB;      // bytes per stage
     constexpr int CROW = BN + 4;                   // floats per row of the epilogue tile
-    constexpr bool DIRECT = M16 && TN == 2 && !OUT_F32 && (Y3_BF16_DIRECT_EPILOGUE != 0);   // register-direct epilogue, permuted weight rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -150,11 +137,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
     }
     unsigned boff[BP];
 #pragma unroll
-    for (int j = 0; j < BP; ++j) {
-        const int R = j * RP + lrow;   // LDS row of the weight tile; DIRECT: row 64 w + 16 nb + c holds channel 64 w + 4 c + nb
-        const int gr = DIRECT ? ((R & ~63) | ((R & 15) << 2) | ((R >> 4) & 3)) : R;
-        boff[j] = (unsigned)((n0 + gr) * p.K + lchunk) * 2u;
-    }
+    for (int j = 0; j < BP; ++j) boff[j] = (unsigned)((n0 + j * RP + lrow) * p.K + lchunk) * 2u;
 
     int tap = 0, c0 = 0;
     unsigned avoff[AP];
@@ -302,49 +285,7 @@ __global__ __launch_bounds__(64 * WR * WC, MINW) void conv_bf16_mfma(const ConvA
     // ---- epilogue through LDS, one 32-row sub-tile of every wave per pass ----------------------------------
     // pass i: wave (wr, wc) writes rows [wr*32, +32) x cols [wc*32*TN, +32*TN) of a [WR*32][BN+4] fp32 tile (its i-th
     // accumulator row block), then all threads convert 8 consecutive channels each and store 16 B.
-    if constexpr (DIRECT) {
-        // ---- bf16 output straight from the accumulators (see the note at the top) -------------------------------------------
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        unsigned short *dstb = static_cast<unsigned short *>(p.dst);
-        const unsigned short *res = static_cast<const unsigned short *>(p.residual);
-        const int nl = n0 + wc * 64 + 4 * fr;    // this lane's four consecutive channels
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + nl);
-        const f32x4 sh = *reinterpret_cast<const f32x4 *>(p.shift + nl);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mw = m0 + (wr * TM + i) * 32 + 4 * fh;   // this lane's first row of the 32-row block
-            u32x2 rr[2][4];
-            if (res) {   // shortcut operand first: its latency hides behind the arithmetic of the pass
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int m = mw + 16 * mb + e;
-                        rr[mb][e] = (m < p.M) ? *reinterpret_cast<const u32x2 *>(res + (size_t)m * p.Cout + nl) : u32x2{0u, 0u};
-                    }
-            }
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[2 * i + mb][j][e] * sc[j] + sh[j];
-                        if (p.leaky) v[j] = fmaxf(v[j], 0.1f * v[j]);
-                    }
-                    if (res) {
-                        v[0] = __uint_as_float(rr[mb][e][0] << 16) + v[0];
-                        v[1] = __uint_as_float(rr[mb][e][0] & 0xffff0000u) + v[1];
-                        v[2] = __uint_as_float(rr[mb][e][1] << 16) + v[2];
-                        v[3] = __uint_as_float(rr[mb][e][1] & 0xffff0000u) + v[3];
-                    }
-                    const int m = mw + 16 * mb + e;
-                    if (m < p.M) *reinterpret_cast<u32x2 *>(dstb + (size_t)m * p.Cout + nl) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                }
-        }
-        Y3_STAMP(4);
-    } else if constexpr (!OUT_F32) {
+    if constexpr (!OUT_F32) {
         // ---- bf16 output: per-wave epilogue, no workgroup barrier ------------------------------------------------------
         // Every wave transposes its own 32 x (32 TN) fp32 blocks through a private LDS scratch (the operand tiles are dead
         // after the loop's last barrier) and stores whole 16-byte pieces of 8 channels: rows of 64 TN bytes per wave, full
