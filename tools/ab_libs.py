@@ -19,7 +19,7 @@ from yolo_v3_tf2_amd import runtime, _lib
 from yolo_v3_tf2_amd.graph import load_program
 from yolo_v3_tf2_amd.weights import synthetic_weights
 p = load_program(os.path.join(%r, "config/models/yolov3/model.yaml"), 80)
-B, S, dt, data = %d, %d, %r, %r
+B, S, dt, data, route = %d, %d, %r, %r, %r
 w = synthetic_weights(p)
 if data == "zeros":   # every operand of every MFMA is zero: no toggling in the matrix pipes or on the data paths (a power experiment)
     for k in w:
@@ -28,10 +28,14 @@ net = runtime.Net(p); net.load_weights(w)
 net.plan(B, S, {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x2": _lib.Y3_DTYPE_F32X2, "f32x3": _lib.Y3_DTYPE_F32X3}[dt])
 x = torch.rand((B, S, S, 3), device="cuda") if data != "zeros" else torch.zeros((B, S, S, 3), device="cuda")
 g = [torch.empty((B, s, s, 3, 85), device="cuda") for s in net.grid_sizes()]
-for _ in range(5): net.forward(x, out=g)
+import numpy as np
+from yolo_v3_tf2_amd.core.utils import get_anchors
+anchors = get_anchors(os.path.join(%r, "datasets/coco2012/anchors.txt")).astype(np.float32)
+step = (lambda: net.forward(x, out=g)) if route == "forward" else (lambda: net.forward_decode(x, anchors))   # decode: the route bench.py times (head convs decode their own tiles)
+for _ in range(5): step()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()
-for _ in range(30): net.forward(x, out=g)
+for _ in range(30): step()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 30
 print("RESULT %%.4f %%.2f" %% (ms, net.flops_per_image() * B / ms / 1e9), flush=True)
@@ -45,9 +49,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--route", default="forward", choices=["forward", "decode"], help="forward: y3_net_forward (grids written); decode: y3_net_forward_decode, the route bench.py times")
     ap.add_argument("--data", default="rand", choices=["rand", "zeros"], help="zeros: all-zero weights and images (what the step costs without data toggling: the power wall)")
     a = ap.parse_args()
-    code = CHILD % (ROOT, ROOT, a.batch, a.image_size, a.dtype, a.data)
+    code = CHILD % (ROOT, ROOT, a.batch, a.image_size, a.dtype, a.data, a.route, ROOT)
     res = {lib: [] for lib in a.libs}
     for r in range(a.rounds):
         for lib in a.libs:
