@@ -15,6 +15,12 @@
 // global workspace -- only boxes with no positive coordinate can pile up there), builds its 256-bit
 // intra-chunk suppression row, and wave 0 resolves the chunk serially with scalar bit-ops.
 // Integer/index work is exact; IoU arithmetic is fp32 without contraction.
+// The kernel runs after the lanes of a step have joined, on B of the chip's 256 CUs with nothing beside it, so its latency chain is
+// step time one to one.  Two chains were shortened in round 5 (same integer logic, same outputs): the score scan requests eight
+// scores per thread before it looks at any (one global round trip per 2048 scores instead of one per 256: 6 instead of 42 at
+// N = 10647), one LDS atomic per wave and pass; the serial resolve keeps the chunk's 256 suppression rows in wave 0's registers
+// (four candidates per lane) and fetches row t with v_readlane -- no LDS read on the dependent chain, selected / kept positions
+// are written to lists and turned into indices by all threads afterwards.
 #include "y3_kernels.h"
 
 namespace y3 {
@@ -82,8 +88,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
     __shared__ __attribute__((aligned(16))) float s_kbox[KEPT_CAP * 4];
     __shared__ __attribute__((aligned(16))) float s_cbox[NMS_THREADS * 4];
     __shared__ u64 s_mask[NMS_THREADS * 4];
-    __shared__ u64 s_alive[4];
-    __shared__ int s_keptpos[NMS_THREADS];
+    __shared__ u64 s_alive[4], s_posany[4];
+    __shared__ int s_keptpos[NMS_THREADS], s_selpos[NMS_THREADS];
     __shared__ int s_cnt, s_nkept_chunk, s_nsel, s_nalive;
 
     const int tid = threadIdx.x;
@@ -108,11 +114,31 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
     __syncthreads();
 
     // ---- 1. threshold + compact (order irrelevant: the sort key carries the index) -----------------
-    for (int i = tid; i < p.N; i += NMS_THREADS) {
-        const float s = scores[i];
-        if (s > p.S) {
-            const int slot = atomicAdd(&s_cnt, 1);
-            gkeys[slot] = ((u64)score_key(s) << 32) | (unsigned)i;
+    // eight scores per thread are requested before any is looked at; a wave reserves its slots with one LDS atomic per pass
+    constexpr int SCAN_UNROLL = 8;
+    const int lane = tid & 63;
+    for (int i0 = 0; i0 < p.N; i0 += NMS_THREADS * SCAN_UNROLL) {
+        float sv[SCAN_UNROLL];
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; ++k) {
+            const int i = i0 + k * NMS_THREADS + tid;
+            sv[k] = (i < p.N) ? scores[i] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < SCAN_UNROLL; ++k) {
+            const int i = i0 + k * NMS_THREADS + tid;
+            const bool hit = i < p.N && sv[k] > p.S;
+            const u64 bal = __ballot(hit);
+            if (bal == 0) continue;                       // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt, __builtin_popcountll(bal));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (hit) {
+                const int slot = base + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                const u64 key = ((u64)score_key(sv[k]) << 32) | (unsigned)i;
+                gkeys[slot] = key;
+                if (slot < SORT_CAP) s_keys[slot] = key;
+            }
         }
     }
     __syncthreads();
@@ -126,7 +152,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
     while (P < nc) P <<= 1;
     u64 *keys;
     if (P <= SORT_CAP) {
-        for (int i = tid; i < P; i += NMS_THREADS) s_keys[i] = (i < nc) ? gkeys[i] : ~0ull;
+        for (int i = nc + tid; i < P; i += NMS_THREADS) s_keys[i] = ~0ull;   // the scan left the keys themselves here
         keys = s_keys;
     } else {
         for (int i = nc + tid; i < P; i += NMS_THREADS) gkeys[i] = ~0ull;
@@ -159,7 +185,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
         }
         *reinterpret_cast<f32x4 *>(s_cbox + tid * 4) = mine;
         const u64 bal = __ballot(ok);
-        if ((tid & 63) == 0) s_alive[tid >> 6] = bal;
+        const u64 pbal = __ballot(mine[0] > 0.0f || mine[1] > 0.0f || mine[2] > 0.0f || mine[3] > 0.0f);   // "selected" iff any coordinate > 0
+        if ((tid & 63) == 0) {
+            s_alive[tid >> 6] = bal;
+            s_posany[tid >> 6] = pbal;
+        }
         __syncthreads();
         // suppression row of this candidate over the later candidates of the chunk
         u64 row[4] = {0, 0, 0, 0};
@@ -171,33 +201,43 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
 #pragma unroll
         for (int w = 0; w < 4; ++w) s_mask[tid * 4 + w] = row[w];
         __syncthreads();
+        const int nsel0 = s_nsel;
         if (tid < 64) {
-            // wave 0, every lane redundantly (uniform control flow): walk the alive bits in order
-            u64 w0 = s_alive[0], w1 = s_alive[1], w2 = s_alive[2], w3 = s_alive[3];
-            int nsel = s_nsel, nk = 0;
+            // wave 0, every lane redundantly (uniform control flow): walk the alive bits in order.  Lane L holds the rows of
+            // candidates L, 64 + L, 128 + L, 192 + L; row t = lane (t & 63) of set (t >> 6), fetched with v_readlane.
+            u64 r[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) r[c][w] = s_mask[(c * 64 + tid) * 4 + w];
+            u64 al[4] = {s_alive[0], s_alive[1], s_alive[2], s_alive[3]};
+            const u64 pa[4] = {s_posany[0], s_posany[1], s_posany[2], s_posany[3]};
+            int nsel = nsel0, nk = 0;
             bool full = false;
-            for (int w = 0; w < 4 && !full; ++w) {
-                u64 rem = (w == 0) ? w0 : (w == 1) ? w1 : (w == 2) ? w2 : w3;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                u64 rem = full ? 0ull : al[w];
                 while (rem) {
-                    const int i = __builtin_ctzll(rem);
+                    const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rem));
                     const int t = w * 64 + i;
                     if (tid == 0) s_keptpos[nk] = t;
                     ++nk;
-                    const f32x4 cb = *reinterpret_cast<const f32x4 *>(s_cbox + t * 4);
-                    if (cb[0] > 0.0f || cb[1] > 0.0f || cb[2] > 0.0f || cb[3] > 0.0f) {
-                        if (tid == 0) sel[nsel] = (int32_t)(unsigned)(keys[pos + t] & 0xFFFFFFFFull);
+                    if ((pa[w] >> i) & 1ull) {
+                        if (tid == 0) s_selpos[nsel - nsel0] = t;
                         ++nsel;
                         if (nsel >= p.M) {
                             full = true;
                             break;
                         }
                     }
-                    w0 &= ~s_mask[t * 4 + 0];
-                    w1 &= ~s_mask[t * 4 + 1];
-                    w2 &= ~s_mask[t * 4 + 2];
-                    w3 &= ~s_mask[t * 4 + 3];
-                    const u64 cur = (w == 0) ? w0 : (w == 1) ? w1 : (w == 2) ? w2 : w3;
-                    rem = (i == 63) ? 0ull : (cur & ~((2ull << i) - 1ull));
+                    // a row only has bits behind its own candidate: words below w are untouched
+#pragma unroll
+                    for (int v = w; v < 4; ++v) {
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(r[w][v] & 0xFFFFFFFFull), i);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(r[w][v] >> 32), i);
+                        al[v] &= ~(((u64)hi << 32) | lo);
+                    }
+                    rem = (i == 63) ? 0ull : (al[w] & ~((2ull << i) - 1ull));
                 }
             }
             if (tid == 0) {
@@ -206,6 +246,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
             }
         }
         __syncthreads();
+        // the chunk's selected positions -> original indices (every thread one)
+        if (tid < s_nsel - nsel0) sel[nsel0 + tid] = (int32_t)(unsigned)(keys[pos + s_selpos[tid]] & 0xFFFFFFFFull);
         const int nk = s_nkept_chunk;
         if (tid < nk && !degenerate) {
             const int t = s_keptpos[tid];
