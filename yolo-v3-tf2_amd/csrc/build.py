@@ -16,7 +16,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=o
 def build(force=False, verbose=False, defines=(), out=None, only=None):
     """defines / out / only: build a variant of the library (extra -D flags, other output name, subset of sources
     recompiled with the flags; the other objects are shared with the default build) for tools/ab_libs.py."""
-    if defines or out:
+    if defines or out or os.environ.get("Y3_VARIANT_FLAGS"):
         return _build_variant(list(defines), out or OUT.replace(".so", "_var.so"), only or SOURCES, verbose)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     objdir = os.path.join(HERE, "build")
@@ -56,12 +56,13 @@ def _build_variant(defines, out, only, verbose):
     if missing:
         raise SystemExit(f"build the default library first (python build.py): no object for {missing}")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tag = "_".join(d.replace("=", "") for d in defines) or "var"
+    extra = os.environ.get("Y3_VARIANT_FLAGS", "").split()    # tools: extra compiler flags for the variant's sources (e.g. "-mllvm -amdgpu-sched-strategy=max-ilp")
+    tag = "_".join(d.replace("=", "") for d in defines) or ("flags" if extra else "var")
     objs = []
     for src in SOURCES:
         if src in only:
             obj = os.path.join(objdir, f"{src}.{tag}.o")
-            cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
+            cmd = [hipcc, *FLAGS, *extra, *[f"-D{d}" for d in defines], "-x", "hip", "-c", os.path.join(HERE, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
