@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
     __shared__ __attribute__((aligned(16))) float s_cbox[NMS_THREADS * 4];
     __shared__ u64 s_mask[NMS_THREADS * 4];
     __shared__ u64 s_alive[4], s_posany[4];
-    __shared__ int s_keptpos[NMS_THREADS], s_selpos[NMS_THREADS];
+    __shared__ int s_keptpos[NMS_THREADS], s_selpos[NMS_THREADS], s_ok[NMS_THREADS];
     __shared__ int s_cnt, s_nkept_chunk, s_nsel, s_nalive;
 
     const int tid = threadIdx.x;
@@ -167,39 +167,64 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs p)
         const int cnt = min(NMS_THREADS, nc - pos);
         const int nalive = s_nalive;
         f32x4 mine = {0.f, 0.f, 0.f, 0.f};
-        int my_idx = 0;
-        bool ok = false;
         if (tid < cnt) {
-            my_idx = (int)(unsigned)(keys[pos + tid] & 0xFFFFFFFFull);
+            const int my_idx = (int)(unsigned)(keys[pos + tid] & 0xFFFFFFFFull);
             mine = *reinterpret_cast<const f32x4 *>(boxes + (size_t)my_idx * 4);
             if (swap_y) { const float t = mine[0]; mine[0] = mine[2]; mine[2] = t; }
             if (swap_x) { const float t = mine[1]; mine[1] = mine[3]; mine[3] = t; }
-            ok = true;
-            if (!degenerate) {
-                const int nlds = min(nalive, KEPT_CAP);
-                for (int a = 0; a < nlds; ++a)
-                    if (iou_tf(*reinterpret_cast<const f32x4 *>(s_kbox + a * 4), mine) >= p.T) ok = false;
-                for (int a = KEPT_CAP; a < nalive; ++a)   // spilled survivors (rare: see the header)
-                    if (iou_tf(*reinterpret_cast<const f32x4 *>(gspill + (size_t)(a - KEPT_CAP) * 4), mine) >= p.T) ok = false;
-            }
         }
         *reinterpret_cast<f32x4 *>(s_cbox + tid * 4) = mine;
+        s_ok[tid] = tid < cnt ? 1 : 0;
+        unsigned *m32 = reinterpret_cast<unsigned *>(s_mask);   // the chunk's suppression rows as 8 x 32 bits per candidate
+#pragma unroll
+        for (int w = 0; w < 8; ++w) m32[tid * 8 + w] = 0u;
+        __syncthreads();
+        // candidates against the kept list, the (candidate, kept box) pairs spread over all 256 threads: a chunk of cnt candidates takes
+        // nalive * cp2 / 256 passes (cp2 = cnt rounded up to a power of two) -- a full chunk one kept box per pass and thread as before, the
+        // short last chunk of an image (a handful of candidates against ~170 kept boxes) a few passes instead of one per kept box
+        if (!degenerate && nalive > 0) {
+            int sh = 0;
+            while ((1 << sh) < cnt) ++sh;
+            const int c = tid & ((1 << sh) - 1), a0 = tid >> sh, astep = NMS_THREADS >> sh;
+            if (c < cnt) {
+                const f32x4 cb = *reinterpret_cast<const f32x4 *>(s_cbox + c * 4);
+                bool hit = false;
+                for (int a = a0; a < nalive; a += astep) {
+                    const f32x4 kb = a < KEPT_CAP ? *reinterpret_cast<const f32x4 *>(s_kbox + a * 4)
+                                                  : *reinterpret_cast<const f32x4 *>(gspill + (size_t)(a - KEPT_CAP) * 4);   // spilled survivors (rare: see the header)
+                    if (iou_tf(kb, cb) >= p.T) hit = true;
+                }
+                if (hit) s_ok[c] = 0;
+            }
+            __syncthreads();
+        }
+        const bool ok = s_ok[tid] != 0;
         const u64 bal = __ballot(ok);
         const u64 pbal = __ballot(mine[0] > 0.0f || mine[1] > 0.0f || mine[2] > 0.0f || mine[3] > 0.0f);   // "selected" iff any coordinate > 0
         if ((tid & 63) == 0) {
             s_alive[tid >> 6] = bal;
             s_posany[tid >> 6] = pbal;
         }
-        __syncthreads();
-        // suppression row of this candidate over the later candidates of the chunk
-        u64 row[4] = {0, 0, 0, 0};
-        if (ok && !degenerate) {
-            for (int j = tid + 1; j < cnt; ++j) {
-                if (iou_tf(mine, *reinterpret_cast<const f32x4 *>(s_cbox + j * 4)) >= p.T) row[j >> 6] |= 1ull << (j & 63);
+        // suppression rows: bit j of row i (i < j) = candidate i suppresses the later candidate j.  Rows of candidates that are not alive are
+        // never applied, so every pair is simply evaluated once -- IoU(earlier, later), the argument order of the sequential definition.
+        if (!degenerate) {
+            if (cnt >= NMS_THREADS / 2) {
+                // balanced: thread t takes the pairs (t, t + d mod 256), d = 1..128 (d = 128 from the lower half only): 128 steps for every
+                // thread instead of 255 for thread 0; the bit goes to the earlier candidate's row with an LDS atomic
+                for (int d = 1; d <= NMS_THREADS / 2; ++d) {
+                    if (d == NMS_THREADS / 2 && tid >= NMS_THREADS / 2) break;
+                    const int j = (tid + d) & (NMS_THREADS - 1);
+                    const int lo = j > tid ? tid : j, hi = j > tid ? j : tid;
+                    if (hi >= cnt) continue;
+                    const f32x4 other = *reinterpret_cast<const f32x4 *>(s_cbox + j * 4);
+                    const f32x4 a = j > tid ? mine : other, b = j > tid ? other : mine;
+                    if (iou_tf(a, b) >= p.T) atomicOr(&m32[lo * 8 + (hi >> 5)], 1u << (hi & 31));
+                }
+            } else if (ok) {
+                for (int j = tid + 1; j < cnt; ++j)
+                    if (iou_tf(mine, *reinterpret_cast<const f32x4 *>(s_cbox + j * 4)) >= p.T) m32[tid * 8 + (j >> 5)] |= 1u << (j & 31);
             }
         }
-#pragma unroll
-        for (int w = 0; w < 4; ++w) s_mask[tid * 4 + w] = row[w];
         __syncthreads();
         const int nsel0 = s_nsel;
         if (tid < 64) {
