@@ -123,9 +123,9 @@ y3_status y3_net_set_tile(y3_net *net, int conv_slot, int tile);
 y3_status y3_net_set_tile_bf16(y3_net *net, int conv_slot, int tile);
 y3_status y3_net_set_tile_x3(y3_net *net, int conv_slot, int tile);
 y3_status y3_net_set_tile_x2(y3_net *net, int conv_slot, int tile);   /* same tile table as _x3; a subset is built */
-/* Run a forward as `lanes` (1..4) equal sub-batches on forked internal streams joined back into the caller's
- * stream: the tail of one sub-batch's conv kernel overlaps the next kernel of another.  Results are unchanged
- * (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
+/* Run a forward as `lanes` (1..4) equal sub-batches: the first on the caller's stream itself, the others on forked
+ * internal streams joined back into it: the tail of one sub-batch's conv kernel overlaps the next kernel of another.
+ * Results are unchanged (images are independent).  Falls back to fewer lanes when the batch is not divisible. */
 y3_status y3_net_set_lanes(y3_net *net, int lanes);
 /* Placement of the fp32 conv tiles on the 8 XCDs (each has a private 4 MB L2).  1 (default): per conv, the XCDs form an
  * (8/gn) x gn grid over the (pixel-tile, channel-tile) matrix, gn chosen so that an XCD's slice of the weights stays in
