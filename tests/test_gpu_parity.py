@@ -724,6 +724,34 @@ def test_forward_lanes_bit_identical(rt, program, weights, lanes):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_lanes_on_a_side_stream_back_to_back(rt, program, weights, anchors, B):
+    """Lane 0 of a multi-lane forward runs on the CALLER's stream and the other lanes fork from / join into it: the whole detect step
+    enqueued several times back to back on a non-default stream, without a host synchronisation in between and with a different batch in
+    every call, gives what one lane gives -- also when the batch is smaller than the lane count (fewer lanes) or ragged."""
+    rng = np.random.default_rng(61)
+    xs = [_cuda(rng.random((B, 96, 96, 3), dtype=np.float32)) for _ in range(3)]
+    net = rt.Net(program)
+    net.load_weights(weights)
+    net.plan(B, 96)
+    net.set_lanes(1)
+    want = []
+    for x in xs:
+        p_, n_ = net.detect(x, anchors, 100, 0.5, 0.1)
+        want.append((p_.clone(), n_.clone()))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for lanes in (2, 3):
+        net.set_lanes(lanes)
+        got = []
+        with torch.cuda.stream(side):
+            for x in xs:                       # three steps in a row on the side stream, no synchronisation in between
+                got.append(net.detect(x, anchors, 100, 0.5, 0.1))
+        side.synchronize()
+        for (gp, gn), (wp, wn) in zip(got, want):
+            assert torch.equal(gp, wp) and torch.equal(gn, wn)
+
+
 @pytest.mark.parametrize("mode", ["f32x3", "f32x2", "bf16"])
 def test_forward_lanes_bit_identical_other_modes(rt, program, weights, mode):
     """Same check in the plane-split and bf16 modes, with the three unequal lanes the tuning tables use."""
