@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--table-batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--lanes", type=int, default=1, help="sub-batch lanes of every forward (1: the sweep of round 2)")
     a = ap.parse_args()
     S = a.image_size
     dt = {"f32": _lib.Y3_DTYPE_F32, "bf16": _lib.Y3_DTYPE_BF16, "f32x3": _lib.Y3_DTYPE_F32X3, "f32x2": _lib.Y3_DTYPE_F32X2}[a.dtype]
@@ -36,7 +37,7 @@ def main():
     setter = {"f32": net.set_tile, "bf16": net.set_tile_bf16, "f32x3": net.set_tile_x3, "f32x2": net.set_tile_x2}[a.dtype]
     for B in [int(b) for b in a.batches.split(",")]:
         net.plan(B, S, dt)
-        net.set_lanes(1)
+        net.set_lanes(a.lanes)
         for slot, o in enumerate(net.conv_ops):
             if o.cin != 3:
                 setter(slot, int(table.get(net.conv_signature(o, S), -1)))
@@ -51,7 +52,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.reps
-        print(f"batch {B:4d}  conv stack {ms:8.3f} ms  {net.flops_per_image() * B / ms / 1e9:7.1f} TF/s  {B / ms * 1e3:8.1f} img/s", flush=True)
+        print(f"batch {B:4d} lanes {a.lanes}  conv stack {ms:8.3f} ms  {net.flops_per_image() * B / ms / 1e9:7.1f} TF/s  {B / ms * 1e3:8.1f} img/s", flush=True)
         del x, grids
 
 
